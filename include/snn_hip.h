@@ -1,0 +1,190 @@
+/*
+ * snn_hip.h - C ABI of the MI355X (gfx950) spiking-CNN forward/backward step.
+ *
+ * This is the drop-in boundary below the reference's operator API
+ * (models.generator {Conv, Norm, LIF, LI, Pool, ...}).  The reference has no
+ * native code of its own: every entry point below replaces the ATen / norse
+ * call sequence that one reference module issues per timestep, re-cut for a
+ * layer-major / time-inner schedule (one call covers all T timesteps).
+ * Citations are reference file:line (relative to the upstream tree).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc'ed by the caller, e.g. a
+ *    torch storage); the library never allocates, frees or synchronises;
+ *  - activations are channels-last: frame-major [N][H][W][C] with N = T*B
+ *    frames ("T-major": frame index = t*B + b); `ld*` is the element stride
+ *    between two pixels of a buffer (>= C; lets an op read / write a channel
+ *    slice of a wider concat buffer, reference Dense merge generator.py:157-161);
+ *  - conv weights are [Cout][KH][KW][Cin] (OHWI = torch channels_last memory
+ *    of the reference's [Cout,Cin,KH,KW] parameter);
+ *  - `stream` is a hipStream_t passed as void*;
+ *  - return 0 on success, non-zero on error; snn_last_error() gives the text
+ *    (thread-local).  Python wrappers turn non-zero into RuntimeError.
+ *  - fp32 is the parity dtype (SNN_F32); per-(t,c) statistics are accumulated
+ *    in fp64 like ATen's CPU batch-norm.
+ */
+#ifndef SNN_HIP_H
+#define SNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNN_ABI_VERSION 1
+
+/* neuron kinds for the fused affine+neuron temporal scan */
+enum {
+    SNN_NEURON_NONE = 0,   /* plain per-(t,c) affine (BatchNorm apply)            */
+    SNN_NEURON_LIF = 1,    /* norse LIFCell step, layer_gen.py:232-235            */
+    SNN_NEURON_LI = 2,     /* norse LICell step,  layer_gen.py:252-254            */
+    SNN_NEURON_LI_TANH = 3 /* LICell followed by nn.Tanh, tiny_yolo.py:39-44      */
+};
+
+/* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
+enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
+
+/* pointwise activations, layer_gen.py:257-284 */
+enum { SNN_ACT_RELU = 0, SNN_ACT_SILU = 1, SNN_ACT_TANH = 2 };
+
+/* neuron constants exactly as norse rounds them in fp32 (oracle/neurons.py:neuron_constants) */
+typedef struct snn_neuron_params {
+    float c_mem;   /* dt * tau_mem_inv            (0.1)  */
+    float c_syn;   /* -dt * tau_syn_inv           (-0.2) */
+    float v_leak;  /* 0 */
+    float v_th;    /* 1 */
+    float v_reset; /* 0 */
+    float alpha;   /* SuperSpike slope, 100 */
+} snn_neuron_params;
+
+int snn_abi_version(void);
+const char* snn_last_error(void);
+
+/* ---------------------------------------------------------------- layout
+ * [N][C][H][W] <-> [N][H][W][C].  Entry/exit adapters for callers that hold
+ * the reference's NCHW event frames X[T,B,2,H,W] (soda.py:138-144). */
+int snn_nchw_to_nhwc(const float* src, float* dst, int64_t N, int C, int H, int W, void* stream);
+int snn_nhwc_to_nchw(const float* src, float* dst, int64_t N, int C, int H, int W, void* stream);
+/* weights [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] (operand of the data-gradient conv) */
+int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+
+/* ---------------------------------------------------------------- convolution
+ * Replaces nn.Conv2d(bias=False, padding=int(k/2), stride=s) of layer_gen.py:129-136
+ * (forward) and its autograd (ATen conv backward) for all T*B frames at once.
+ * Implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled.
+ *
+ * fwd  : y[n,ho,wo,co]   = sum_{kh,kw,ci} x[n, ho*s-pad+kh, wo*s-pad+kw, ci] * w[co,kh,kw,ci]
+ * dgrad: dx[n,hi,wi,ci]  = sum_{kh,kw,co} dy[n,(hi+pad-kh)/s,(wi+pad-kw)/s,co] * wt[ci,kh,kw,co]
+ *        (terms with a non-integral or out-of-range source pixel are 0; wt from snn_weight_transpose)
+ * wgrad: dw[co,kh,kw,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n, ho*s-pad+kh, wo*s-pad+kw, ci]
+ *        split over `splitk` pixel ranges into `workspace` ([splitk][Cout*KH*KW*Cin] floats),
+ *        then reduced in fixed order (bitwise reproducible).
+ * accumulate != 0 : the result is added to the destination instead of overwriting it. */
+int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
+                   int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                   int KH, int KW, int stride, int pad, int accumulate, void* stream);
+int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx,
+                     int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                     int KH, int KW, int stride, int pad, int accumulate, void* stream);
+int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw,
+                     int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                     int KH, int KW, int stride, int pad, int accumulate,
+                     float* workspace, int splitk, void* stream);
+/* number of pixel splits snn_conv2d_wgrad wants for this shape (workspace = splitk*Cout*KH*KW*Cin floats) */
+int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+
+/* ---------------------------------------------------------------- batch-norm statistics
+ * Train-mode nn.BatchNorm2d (layer_gen.py:211-214) applied per TIMESTEP: for every (t,c)
+ * the biased mean/var over the M = B*h*w pixels of timestep t (generator.py:190-195 calls the
+ * module once per timestep).  `partial` is scratch of snn_bn_stats_partial_size() doubles.
+ * snn_bn_stats_finalize also performs the T sequential running-stat updates of one reference
+ * forward (momentum 0.1, unbiased variance) when running_mean/var are non-NULL, and emits the
+ * per-(t,c) affine  alpha = gamma*invstd, beta = bias - mean*alpha  that the scan consumes.
+ * use_running != 0 (eval mode): alpha/beta come from the running statistics for every t. */
+size_t snn_bn_stats_partial_size(int T, int64_t M, int C);
+int snn_bn_stats(const float* y, int64_t ldy, int T, int64_t M, int C, double* partial, void* stream);
+int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C,
+                          const float* gamma, const float* bias, float eps, float momentum,
+                          float* running_mean, float* running_var, int use_running,
+                          float* mean, float* invstd, float* alpha, float* beta, void* stream);
+
+/* ---------------------------------------------------------------- fused affine + neuron scan
+ * One kernel = BatchNorm apply + T-step neuron recurrence with the membrane state held in
+ * registers.  Replaces, per layer, T x {BatchNorm2d apply, ~12 elementwise norse ops}
+ * (layer_gen.py:211-235, norse lif_feed_forward_step / li_feed_forward_step).
+ *
+ *   x[t]   = y[t]*alpha[t,c] + beta[t,c]                 (alpha/beta NULL -> identity)
+ *   LIF    : i' = i + x; vd = v + c_mem*((v_leak - v) + i'); i = i' + c_syn*i';
+ *            z = (vd - v_th > 0); v = (1-z)*vd + z*v_reset; out[t] = z
+ *   LI     : i' = i + x; v = v + c_mem*((v_leak - v) + i'); i = i' + c_syn*i'; out[t] = v (or tanh(v))
+ *   v0/i0 NULL -> initial state (v = v_leak, i = 0); vT/iT NULL -> final state not written.
+ *   vdec (LIF, training) receives the pre-reset potential vd[t] for the surrogate backward.
+ * Layout: y/out/vdec are [T][M][C-slice] with pixel strides ldy/ldo (vdec dense, ld = C). */
+int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
+                          const float* alpha, const float* beta,
+                          const float* v0, const float* i0,
+                          float* out, int64_t ldo, float* vT, float* iT, float* vdec,
+                          int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+
+/* Reverse-time scan (BPTT through the neuron, SuperSpike surrogate dz/du = 1/(alpha|u|+1)^2,
+ * reset path NOT detached).  g_out is dL/d out[t]; g_vT/g_iT (may be NULL = 0) are the
+ * gradients of the final state; writes gx = dL/dx[t] (dense [T][M][C]), g_v0/g_i0 (may be NULL)
+ * and, when `sums` != NULL, per-block partial sums of gx and gx*y per (t,c) for the BatchNorm
+ * backward (`sums` scratch of snn_affine_neuron_bwd_sums_size() doubles, y must be given).
+ * `state` is vdec for LIF, out (tanh output) for LI_TANH, unused otherwise.
+ * scale (may be NULL): gx is multiplied by scale[t,c] before it is written (eval-mode BN: dy = alpha*gx). */
+size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C);
+int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state,
+                          const float* y, int64_t ldy, const float* g_vT, const float* g_iT,
+                          const float* scale, float* gx, float* g_v0, float* g_i0, double* sums,
+                          int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+
+/* BatchNorm backward, second phase.  From the partial sums: per-(t,c)
+ *   dy = A*gx + Bc*y + Cc,  A = alpha, Bc = -alpha*invstd*s2, Cc = -alpha*s1 + alpha*invstd*mean*s2,
+ *   s1 = mean_pix(gx), s2 = mean_pix(gx*xhat);  dgamma[c] = sum_t sum_pix gx*xhat, dbias[c] = sum_t sum_pix gx.
+ * dgamma/dbias are accumulated (+=) when accumulate != 0.  `sums` is reduced in place. */
+int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C,
+                        const float* gamma, const float* mean, const float* invstd,
+                        float* coefA, float* coefB, float* coefC,
+                        float* dgamma, float* dbias, int accumulate, void* stream);
+int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy,
+                     const float* coefA, const float* coefB, const float* coefC,
+                     float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- merges and pointwise
+ * Residual merge = torch.stack(out).sum(0) (generator.py:145-146); Dense merge = torch.cat(out,1)
+ * (generator.py:157-158).  A channel-slice copy / add over M pixels covers both and their backward. */
+int snn_copy_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
+int snn_add_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
+/* dst = a + b (dense, n elements) */
+int snn_add(const float* a, const float* b, float* dst, int64_t n, void* stream);
+int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream);
+int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n, void* stream);
+
+/* Pool("A"/"M"/"S", k, stride) (layer_gen.py:146-173, common.py:18-49), no padding, floor mode. */
+int snn_pool_fwd(int kind, const float* x, float* y, int64_t N, int H, int W, int C,
+                 int Ho, int Wo, int k, int stride, void* stream);
+int snn_pool_bwd(int kind, const float* x, const float* gy, float* gx, int64_t N, int H, int W, int C,
+                 int Ho, int Wo, int k, int stride, void* stream);
+/* nn.Upsample(scale_factor=s, mode="nearest") (layer_gen.py:176-194) */
+int snn_upsample_fwd(const float* x, float* y, int64_t N, int H, int W, int C, int scale, void* stream);
+int snn_upsample_bwd(const float* gy, float* gx, int64_t N, int H, int W, int C, int scale, void* stream);
+
+/* ---------------------------------------------------------------- optimizer
+ * torch.optim.Adamax(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) single-tensor step
+ * (soda.py:135-136) over a flat parameter / gradient buffer. */
+int snn_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_inf,
+                    int64_t n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ---------------------------------------------------------------- event voxelisation
+ * utils/datasets.py:378-435: scatter events (t_bin, p, y, x) into binary frames [T][H][W][2]
+ * (channels-last image of the reference's [T,2,H,W]); x is clipped to W-1; value 1 (not a count). */
+int snn_events_to_frames(const int32_t* t_bin, const int32_t* x, const int32_t* y, const int32_t* p,
+                         int64_t n_events, float* frames, int T, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNN_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``libsnn_hip.so`` (the C ABI declared in ``include/snn_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails the product raises.
+Device pointers come from torch storages (``tensor.data_ptr()``), the stream from
+``torch.cuda.current_stream().cuda_stream``; torch is plumbing only.
+"""
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnn_hip.so")
+
+NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH = 0, 1, 2, 3
+POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
+ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
+ABI_VERSION = 1
+
+
+class NeuronParams(Structure):
+    _fields_ = [("c_mem", c_float), ("c_syn", c_float), ("v_leak", c_float), ("v_th", c_float),
+                ("v_reset", c_float), ("alpha", c_float)]
+
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/snn_hip.h one to one
+SIGNATURES = {
+    "snn_abi_version": (c_int, []),
+    "snn_last_error": (c_char_p, []),
+    "snn_nchw_to_nhwc": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
+    "snn_nhwc_to_nchw": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
+    "snn_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I]),
+    "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
+    "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
+    "snn_bn_stats_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _L, _I,
+                                      POINTER(NeuronParams), _P]),
+    "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),
+    "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I,
+                                      POINTER(NeuronParams), _P]),
+    "snn_bn_bwd_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
+    "snn_copy_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
+    "snn_add_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
+    "snn_add": (c_int, [_P, _P, _P, _L, _P]),
+    "snn_act_fwd": (c_int, [_I, _P, _P, _L, _P]),
+    "snn_act_bwd": (c_int, [_I, _P, _P, _P, _P, _L, _P]),
+    "snn_pool_fwd": (c_int, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "snn_pool_bwd": (c_int, [_I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "snn_upsample_fwd": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "snn_upsample_bwd": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "snn_adamax_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
+    "snn_events_to_frames": (c_int, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the gfx950 HIP extension has not been built "
+            "(run `python -m snn_for_object_detection_amd._build`); there is no CPU / eager fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.snn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libsnn_hip.so ABI {lib.snn_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point; non-zero -> RuntimeError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.snn_last_error()
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def query(name: str, *args):
+    return getattr(load(), name)(*args)

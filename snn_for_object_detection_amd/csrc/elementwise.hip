@@ -1,0 +1,412 @@
+// Layout adapters, merges (Residual sum / Dense concat slices), pointwise activations, pooling,
+// nearest upsampling, fused Adamax and event voxelisation for gfx950.  All HBM-bound: 16-byte
+// lane-contiguous accesses where the shape allows, grid-stride loops capped at 8 blocks / CU.
+#include <stdarg.h>
+#include "snn_common.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void snn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* snn_last_error(void) { return g_err; }
+extern "C" int snn_abi_version(void) { return SNN_ABI_VERSION; }
+
+namespace {
+
+constexpr int kThreads = 256;
+
+static unsigned grid_for(int64_t n) {
+    int64_t b = snn_ceil_div(n, kThreads);
+    if (b > SNN_MAX_BLOCKS) b = SNN_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------ layout
+// [N][C][HW] -> [N][HW][C] through a 32x33 LDS tile: both sides coalesced.
+__global__ void k_transpose_cp(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    // per image: src is [rows][cols], dst is [cols][rows]
+    __shared__ float tile[32][33];
+    const int64_t img = blockIdx.z;
+    const float* s = src + img * (int64_t)rows * cols;
+    float* d = dst + img * (int64_t)rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = s[(int64_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) d[(int64_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// small-channel NCHW -> NHWC (C <= 4, e.g. the 2-polarity event frames): one thread per pixel
+template <int C>
+__global__ void k_nchw_to_nhwc_small(const float* __restrict__ src, float* __restrict__ dst, int64_t N, int64_t HW) {
+    const int64_t total = N * HW;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t n = e / HW, px = e % HW;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = src[(n * C + c) * HW + px];
+#pragma unroll
+        for (int c = 0; c < C; ++c) dst[e * C + c] = v[c];
+    }
+}
+
+__global__ void k_weight_transpose(const float* __restrict__ w, float* __restrict__ wt, int Cout, int taps, int Cin) {
+    const int64_t total = (int64_t)Cout * taps * Cin;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        // e indexes wt[ci][tap][co]
+        int co = (int)(e % Cout);
+        int64_t r = e / Cout;
+        int tap = (int)(r % taps);
+        int ci = (int)(r / taps);
+        wt[e] = w[((int64_t)co * taps + tap) * Cin + ci];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ merges
+template <int VEC, bool ADD>
+__global__ void k_channels(const float* __restrict__ src, int64_t lds, float* __restrict__ dst, int64_t ldd, int64_t M,
+                           int C) {
+    const int cv = C / VEC;
+    const int64_t total = M * cv;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = e / cv;
+        const int c = (int)(e % cv) * VEC;
+        if (VEC == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + m * lds + c);
+            f32x4* d = reinterpret_cast<f32x4*>(dst + m * ldd + c);
+            if (ADD) v += *d;
+            *d = v;
+        } else {
+            float v = src[m * lds + c];
+            if (ADD) v += dst[m * ldd + c];
+            dst[m * ldd + c] = v;
+        }
+    }
+}
+
+template <int VEC>
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int64_t n) {
+    const int64_t total = n / VEC;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        if (VEC == 4) {
+            f32x4 x = reinterpret_cast<const f32x4*>(a)[e];
+            f32x4 y = reinterpret_cast<const f32x4*>(b)[e];
+            reinterpret_cast<f32x4*>(dst)[e] = x + y;
+        } else {
+            dst[e] = a[e] + b[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_f(int act, float x) {
+    switch (act) {
+        case SNN_ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case SNN_ACT_SILU: return x / (1.0f + expf(-x));
+        default: return tanhf(x);
+    }
+}
+__device__ __forceinline__ float act_g(int act, float x, float y) {
+    switch (act) {
+        case SNN_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+        case SNN_ACT_SILU: {
+            float s = 1.0f / (1.0f + expf(-x));
+            return s * (1.0f + x * (1.0f - s));
+        }
+        default: return 1.0f - y * y;
+    }
+}
+__global__ void k_act_fwd(int act, const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads)
+        y[e] = act_f(act, x[e]);
+}
+__global__ void k_act_bwd(int act, const float* __restrict__ x, const float* __restrict__ y,
+                          const float* __restrict__ gy, float* __restrict__ gx, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads)
+        gx[e] = gy[e] * act_g(act, x[e], y[e]);
+}
+
+// ------------------------------------------------------------------------------------------ pooling
+__global__ void k_pool_fwd(int kind, const float* __restrict__ x, float* __restrict__ y, int64_t N, int H, int W, int C,
+                           int Ho, int Wo, int k, int stride) {
+    const int64_t total = N * Ho * Wo * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        int c = (int)(e % C);
+        int64_t r = e / C;
+        int wo = (int)(r % Wo);
+        r /= Wo;
+        int ho = (int)(r % Ho);
+        int64_t n = r / Ho;
+        float acc = (kind == SNN_POOL_MAX) ? -INFINITY : 0.0f;
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                float v = x[((n * H + ho * stride + i) * W + wo * stride + j) * C + c];
+                if (kind == SNN_POOL_MAX) acc = (v > acc || v != v) ? v : acc;
+                else acc += v;
+            }
+        if (kind == SNN_POOL_AVG) acc = acc / (float)(k * k);
+        // SumPool2d = avg_pool2d * k * k (common.py:44-48): divide then multiply twice, as the reference does
+        if (kind == SNN_POOL_SUM) acc = ((acc / (float)(k * k)) * (float)k) * (float)k;
+        y[e] = acc;
+    }
+}
+
+// one thread per INPUT element: gathers from every window that covers it (windows overlap when stride < k)
+__global__ void k_pool_bwd(int kind, const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                           int64_t N, int H, int W, int C, int Ho, int Wo, int k, int stride) {
+    const int64_t total = N * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        int c = (int)(e % C);
+        int64_t r = e / C;
+        int w = (int)(r % W);
+        r /= W;
+        int h = (int)(r % H);
+        int64_t n = r / H;
+        float acc = 0.0f;
+        int ho_lo = (h - k + stride) / stride;
+        if (h - k + 1 < 0) ho_lo = 0;
+        int wo_lo = (w - k + stride) / stride;
+        if (w - k + 1 < 0) wo_lo = 0;
+        for (int ho = ho_lo; ho < Ho && ho * stride <= h; ++ho)
+            for (int wo = wo_lo; wo < Wo && wo * stride <= w; ++wo) {
+                if (h - ho * stride >= k || w - wo * stride >= k) continue;
+                float g = gy[((n * Ho + ho) * Wo + wo) * C + c];
+                if (kind == SNN_POOL_MAX) {
+                    // gradient goes to the FIRST maximal element of the window (ATen max_pool2d)
+                    float best = -INFINITY;
+                    int bi = 0, bj = 0;
+                    for (int i = 0; i < k; ++i)
+                        for (int j = 0; j < k; ++j) {
+                            float v = x[((n * H + ho * stride + i) * W + wo * stride + j) * C + c];
+                            if (v > best || v != v) { best = v; bi = i; bj = j; }
+                        }
+                    if (ho * stride + bi == h && wo * stride + bj == w) acc += g;
+                } else if (kind == SNN_POOL_AVG) {
+                    acc += g / (float)(k * k);
+                } else {
+                    acc += ((g * (float)k) * (float)k) / (float)(k * k);
+                }
+            }
+        gx[e] = acc;
+    }
+}
+
+__global__ void k_upsample_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t N, int H, int W, int C,
+                               int s) {
+    const int Ho = H * s, Wo = W * s;
+    const int64_t total = N * Ho * Wo * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        int c = (int)(e % C);
+        int64_t r = e / C;
+        int wo = (int)(r % Wo);
+        r /= Wo;
+        int ho = (int)(r % Ho);
+        int64_t n = r / Ho;
+        y[e] = x[((n * H + ho / s) * W + wo / s) * C + c];
+    }
+}
+__global__ void k_upsample_bwd(const float* __restrict__ gy, float* __restrict__ gx, int64_t N, int H, int W, int C,
+                               int s) {
+    const int Ho = H * s, Wo = W * s;
+    const int64_t total = N * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        int c = (int)(e % C);
+        int64_t r = e / C;
+        int w = (int)(r % W);
+        r /= W;
+        int h = (int)(r % H);
+        int64_t n = r / H;
+        float acc = 0.0f;
+        for (int i = 0; i < s; ++i)
+            for (int j = 0; j < s; ++j) acc += gy[((n * Ho + h * s + i) * Wo + w * s + j) * C + c];
+        gx[e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ optimizer
+__global__ void k_adamax(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                         float* __restrict__ u, int64_t n, float lr, float b1, float b2, float eps, float clr) {
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads) {
+        float ge = g[e];
+        // torch.optim.Adamax single-tensor: exp_avg.lerp_(grad, 1-beta1); exp_inf = max(exp_inf*beta2, |g|+eps)
+        float me = m[e] + (ge - m[e]) * (1.0f - b1);
+        float ue = fmaxf(u[e] * b2, fabsf(ge) + eps);
+        m[e] = me;
+        u[e] = ue;
+        p[e] = p[e] - clr * (me / ue);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ events
+__global__ void k_events(const int32_t* __restrict__ tb, const int32_t* __restrict__ xs, const int32_t* __restrict__ ys,
+                         const int32_t* __restrict__ ps, int64_t n, float* __restrict__ frames, int T, int H, int W) {
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads) {
+        int t = tb[e], x = xs[e], y = ys[e], p = ps[e];
+        if (t < 0 || t >= T || y < 0 || y >= H || p < 0 || p > 1) continue;
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+        frames[(((int64_t)t * H + y) * W + x) * 2 + p] = 1.0f;  // idempotent store: races are benign
+    }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------- C ABI
+extern "C" int snn_nchw_to_nhwc(const float* src, float* dst, int64_t N, int C, int H, int W, void* stream) {
+    SNN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "snn_nchw_to_nhwc: bad arguments");
+    const int64_t HW = (int64_t)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 1) {
+        hipError_t ce = hipMemcpyAsync(dst, src, sizeof(float) * N * HW, hipMemcpyDeviceToDevice, st);
+        SNN_REQUIRE(ce == hipSuccess, "snn_nchw_to_nhwc: copy failed: %s", hipGetErrorString(ce));
+    } else if (C == 2) {
+        hipLaunchKernelGGL(k_nchw_to_nhwc_small<2>, dim3(grid_for(N * HW)), dim3(kThreads), 0, st, src, dst, N, HW);
+    } else if (C == 3) {
+        hipLaunchKernelGGL(k_nchw_to_nhwc_small<3>, dim3(grid_for(N * HW)), dim3(kThreads), 0, st, src, dst, N, HW);
+    } else if (C == 4) {
+        hipLaunchKernelGGL(k_nchw_to_nhwc_small<4>, dim3(grid_for(N * HW)), dim3(kThreads), 0, st, src, dst, N, HW);
+    } else {
+        SNN_REQUIRE(N <= 65535, "snn_nchw_to_nhwc: more than 65535 frames");
+        dim3 grid((unsigned)snn_ceil_div(HW, 32), (unsigned)snn_ceil_div(C, 32), (unsigned)N);
+        hipLaunchKernelGGL(k_transpose_cp, grid, dim3(32, 8), 0, st, src, dst, C, (int)HW);
+    }
+    SNN_CHECK_LAUNCH("snn_nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int snn_nhwc_to_nchw(const float* src, float* dst, int64_t N, int C, int H, int W, void* stream) {
+    SNN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "snn_nhwc_to_nchw: bad arguments");
+    SNN_REQUIRE(N <= 65535, "snn_nhwc_to_nchw: more than 65535 frames");
+    const int64_t HW = (int64_t)H * W;
+    dim3 grid((unsigned)snn_ceil_div(C, 32), (unsigned)snn_ceil_div(HW, 32), (unsigned)N);
+    hipLaunchKernelGGL(k_transpose_cp, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, (int)HW, C);
+    SNN_CHECK_LAUNCH("snn_nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
+    SNN_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "snn_weight_transpose: bad arguments");
+    int64_t n = (int64_t)Cout * KH * KW * Cin;
+    hipLaunchKernelGGL(k_weight_transpose, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, w, wt, Cout,
+                       KH * KW, Cin);
+    SNN_CHECK_LAUNCH("snn_weight_transpose");
+    return 0;
+}
+
+static int channels_op(bool add, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C,
+                       void* stream) {
+    SNN_REQUIRE(src && dst && M > 0 && C > 0 && lds >= C && ldd >= C, "snn_%s_channels: bad arguments",
+                add ? "add" : "copy");
+    bool v4 = C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && aligned16(src) && aligned16(dst);
+    int64_t n = M * (v4 ? C / 4 : C);
+    hipStream_t st = (hipStream_t)stream;
+    if (v4 && add) hipLaunchKernelGGL((k_channels<4, true>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, lds, dst, ldd, M, C);
+    else if (v4) hipLaunchKernelGGL((k_channels<4, false>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, lds, dst, ldd, M, C);
+    else if (add) hipLaunchKernelGGL((k_channels<1, true>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, lds, dst, ldd, M, C);
+    else hipLaunchKernelGGL((k_channels<1, false>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, lds, dst, ldd, M, C);
+    SNN_CHECK_LAUNCH("snn_channels");
+    return 0;
+}
+extern "C" int snn_copy_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream) {
+    return channels_op(false, src, lds, dst, ldd, M, C, stream);
+}
+extern "C" int snn_add_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream) {
+    return channels_op(true, src, lds, dst, ldd, M, C, stream);
+}
+
+extern "C" int snn_add(const float* a, const float* b, float* dst, int64_t n, void* stream) {
+    SNN_REQUIRE(a && b && dst && n > 0, "snn_add: bad arguments");
+    bool v4 = n % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(dst);
+    if (v4) hipLaunchKernelGGL(k_add<4>, dim3(grid_for(n / 4)), dim3(kThreads), 0, (hipStream_t)stream, a, b, dst, n);
+    else hipLaunchKernelGGL(k_add<1>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, a, b, dst, n);
+    SNN_CHECK_LAUNCH("snn_add");
+    return 0;
+}
+
+extern "C" int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream) {
+    SNN_REQUIRE(x && y && n > 0 && act >= SNN_ACT_RELU && act <= SNN_ACT_TANH, "snn_act_fwd: bad arguments");
+    hipLaunchKernelGGL(k_act_fwd, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, act, x, y, n);
+    SNN_CHECK_LAUNCH("snn_act_fwd");
+    return 0;
+}
+extern "C" int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n,
+                           void* stream) {
+    SNN_REQUIRE(x && y && gy && gx && n > 0 && act >= SNN_ACT_RELU && act <= SNN_ACT_TANH, "snn_act_bwd: bad arguments");
+    hipLaunchKernelGGL(k_act_bwd, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, act, x, y, gy, gx, n);
+    SNN_CHECK_LAUNCH("snn_act_bwd");
+    return 0;
+}
+
+extern "C" int snn_pool_fwd(int kind, const float* x, float* y, int64_t N, int H, int W, int C, int Ho, int Wo, int k,
+                            int stride, void* stream) {
+    SNN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0, "snn_pool_fwd: bad arguments");
+    SNN_REQUIRE(kind >= SNN_POOL_AVG && kind <= SNN_POOL_SUM, "snn_pool_fwd: bad pool kind %d", kind);
+    SNN_REQUIRE(Ho == (H - k) / stride + 1 && Wo == (W - k) / stride + 1 && Ho > 0 && Wo > 0,
+                "snn_pool_fwd: output size mismatch");
+    hipLaunchKernelGGL(k_pool_fwd, dim3(grid_for(N * Ho * Wo * C)), dim3(kThreads), 0, (hipStream_t)stream, kind, x, y,
+                       N, H, W, C, Ho, Wo, k, stride);
+    SNN_CHECK_LAUNCH("snn_pool_fwd");
+    return 0;
+}
+extern "C" int snn_pool_bwd(int kind, const float* x, const float* gy, float* gx, int64_t N, int H, int W, int C,
+                            int Ho, int Wo, int k, int stride, void* stream) {
+    SNN_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0, "snn_pool_bwd: bad arguments");
+    SNN_REQUIRE(kind >= SNN_POOL_AVG && kind <= SNN_POOL_SUM, "snn_pool_bwd: bad pool kind %d", kind);
+    SNN_REQUIRE(kind != SNN_POOL_MAX || x, "snn_pool_bwd: max pooling needs the forward input");
+    hipLaunchKernelGGL(k_pool_bwd, dim3(grid_for(N * H * W * C)), dim3(kThreads), 0, (hipStream_t)stream, kind, x, gy,
+                       gx, N, H, W, C, Ho, Wo, k, stride);
+    SNN_CHECK_LAUNCH("snn_pool_bwd");
+    return 0;
+}
+
+extern "C" int snn_upsample_fwd(const float* x, float* y, int64_t N, int H, int W, int C, int scale, void* stream) {
+    SNN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && scale > 0, "snn_upsample_fwd: bad arguments");
+    hipLaunchKernelGGL(k_upsample_fwd, dim3(grid_for(N * H * scale * W * scale * C)), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, y, N, H, W, C, scale);
+    SNN_CHECK_LAUNCH("snn_upsample_fwd");
+    return 0;
+}
+extern "C" int snn_upsample_bwd(const float* gy, float* gx, int64_t N, int H, int W, int C, int scale, void* stream) {
+    SNN_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && scale > 0, "snn_upsample_bwd: bad arguments");
+    hipLaunchKernelGGL(k_upsample_bwd, dim3(grid_for(N * H * W * C)), dim3(kThreads), 0, (hipStream_t)stream, gy, gx, N,
+                       H, W, C, scale);
+    SNN_CHECK_LAUNCH("snn_upsample_bwd");
+    return 0;
+}
+
+extern "C" int snn_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_inf, int64_t n, float lr,
+                               float beta1, float beta2, float eps, int step, void* stream) {
+    SNN_REQUIRE(param && grad && exp_avg && exp_inf && n > 0 && step >= 1, "snn_adamax_step: bad arguments");
+    // clr = lr / (1 - beta1^step)
+    double bias_corr = 1.0 - pow((double)beta1, (double)step);
+    float clr = (float)((double)lr / bias_corr);
+    hipLaunchKernelGGL(k_adamax, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_inf, n, lr, beta1, beta2, eps, clr);
+    SNN_CHECK_LAUNCH("snn_adamax_step");
+    return 0;
+}
+
+extern "C" int snn_events_to_frames(const int32_t* t_bin, const int32_t* x, const int32_t* y, const int32_t* p,
+                                    int64_t n_events, float* frames, int T, int H, int W, void* stream) {
+    SNN_REQUIRE(frames && T > 0 && H > 0 && W > 0 && n_events >= 0, "snn_events_to_frames: bad arguments");
+    hipError_t me = hipMemsetAsync(frames, 0, sizeof(float) * (size_t)T * H * W * 2, (hipStream_t)stream);
+    SNN_REQUIRE(me == hipSuccess, "snn_events_to_frames: memset failed: %s", hipGetErrorString(me));
+    if (n_events == 0) return 0;
+    SNN_REQUIRE(t_bin && x && y && p, "snn_events_to_frames: null event arrays");
+    hipLaunchKernelGGL(k_events, dim3(grid_for(n_events)), dim3(kThreads), 0, (hipStream_t)stream, t_bin, x, y, p,
+                       n_events, frames, T, H, W);
+    SNN_CHECK_LAUNCH("snn_events_to_frames");
+    return 0;
+}

@@ -1,0 +1,622 @@
+// Fused BatchNorm-apply + spiking-neuron temporal scan, forward and BPTT backward (gfx950).
+//
+// Memory-bound kernels: one thread owns VEC(=4) consecutive channels of one pixel and walks the
+// T timesteps with the membrane state (v, i) in registers; every HBM access is a 16-byte
+// lane-contiguous vector.  Compiled with -ffp-contract=off so each statement rounds like the
+// reference's unfused torch ops (oracle/neurons.py).
+//
+// Reference semantics: layer_gen.py:211-214 (BatchNorm2d, per-timestep batch statistics),
+// layer_gen.py:232-235 / 252-254 (norse LIFCell / LICell), tiny_yolo.py:39-44 (LI -> Tanh).
+#include "snn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec<1> {
+    typedef float type;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <int VEC> __device__ __forceinline__ float& lane(typename Vec<VEC>::type& v, int j);
+template <> __device__ __forceinline__ float& lane<4>(f32x4& v, int j) { return reinterpret_cast<float*>(&v)[j]; }
+template <> __device__ __forceinline__ float& lane<1>(float& v, int) { return v; }
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm statistics: per (t, c) sum and sum of squares over the M pixels of timestep t.
+// grid = (chunks, T, channel blocks); partial[t][chunk][c][2] in fp64.
+// ------------------------------------------------------------------------------------------
+struct StatsPlan {
+    int vec, cvb, zblocks, chunks;
+};
+
+static StatsPlan stats_plan(int T, int64_t M, int C) {
+    StatsPlan pl;
+    pl.vec = (C % 4 == 0) ? 4 : 1;
+    int cv = C / pl.vec;
+    pl.cvb = cv < kThreads ? cv : kThreads;
+    pl.zblocks = (int)snn_ceil_div(cv, pl.cvb);
+    int P = kThreads / pl.cvb;
+    int64_t want = snn_ceil_div(SNN_MAX_BLOCKS, (int64_t)T * pl.zblocks);
+    int64_t maxc = snn_ceil_div(M, (int64_t)P * 8);  // at least ~8 pixels per thread
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    pl.chunks = (int)want;
+    return pl;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_bn_stats(const float* __restrict__ y, int64_t ldy, int64_t M, int C,
+                                                       int cvb, double* __restrict__ partial) {
+    __shared__ double red[kThreads * 2 * VEC];
+    const int chunks = gridDim.x, chunk = blockIdx.x, t = blockIdx.y;
+    const int cv = C / VEC;
+    const int P = kThreads / cvb;
+    const int tid = threadIdx.x;
+    const int cgl = tid % cvb, ps = tid / cvb;
+    const int cg = blockIdx.z * cvb + cgl;
+    const bool active = (ps < P) && (cg < cv);
+    const int64_t per = snn_ceil_div_dev(M, chunks);
+    double s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.0;
+    if (active) {
+        const int64_t m0 = (int64_t)chunk * per;
+        int64_t m1 = m0 + per;
+        if (m1 > M) m1 = M;
+        const float* base = y + ((int64_t)t * M) * ldy + (int64_t)cg * VEC;
+        for (int64_t m = m0 + ps; m < m1; m += P) {
+            typename Vec<VEC>::type v = Vec<VEC>::load(base + m * ldy);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                double d = (double)lane<VEC>(v, j);
+                s[j] += d;
+                q[j] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        red[(tid * VEC + j) * 2 + 0] = s[j];
+        red[(tid * VEC + j) * 2 + 1] = q[j];
+    }
+    __syncthreads();
+    if (ps == 0 && cg < cv) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            double ss = 0.0, qq = 0.0;
+            for (int k = 0; k < P; ++k) {
+                ss += red[((k * cvb + cgl) * VEC + j) * 2 + 0];
+                qq += red[((k * cvb + cgl) * VEC + j) * 2 + 1];
+            }
+            double* dst = partial + (((int64_t)t * chunks + chunk) * C + (int64_t)cg * VEC + j) * 2;
+            dst[0] = ss;
+            dst[1] = qq;
+        }
+    }
+}
+
+__global__ void k_bn_stats_finalize(const double* __restrict__ partial, int chunks, int T, int64_t M, int C,
+                                    const float* __restrict__ gamma, const float* __restrict__ bias, float eps,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    int use_running, float* __restrict__ mean, float* __restrict__ invstd,
+                                    float* __restrict__ alpha, float* __restrict__ beta,
+                                    double* __restrict__ var_unbiased) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * C) return;
+    int t = idx / C, c = idx % C;
+    float mu, is;
+    if (use_running) {
+        mu = running_mean[c];
+        is = 1.0f / sqrtf(running_var[c] + eps);  // ATen eval path: invstd in fp32
+    } else {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
+            s += src[0];
+            q += src[1];
+        }
+        double n = (double)M;
+        double m = s / n;
+        double var = q / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mu = (float)m;
+        is = (float)(1.0 / sqrt(var + (double)eps));
+        if (var_unbiased) var_unbiased[idx] = (M > 1) ? var * n / (n - 1.0) : var;
+    }
+    mean[idx] = mu;
+    invstd[idx] = is;
+    float g = gamma ? gamma[c] : 1.0f;
+    float b = bias ? bias[c] : 0.0f;
+    float a = is * g;
+    alpha[idx] = a;
+    beta[idx] = b - mu * a;
+}
+
+// T sequential running-stat updates of one reference forward (one BatchNorm call per timestep).
+__global__ void k_bn_running_update(const float* __restrict__ mean, const double* __restrict__ var_unbiased, int T,
+                                    int C, float momentum, float* __restrict__ running_mean,
+                                    float* __restrict__ running_var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    const double mom = (double)momentum;
+    for (int t = 0; t < T; ++t) {
+        rm = (float)(mom * (double)mean[t * C + c] + (1.0 - mom) * (double)rm);
+        rv = (float)(mom * var_unbiased[t * C + c] + (1.0 - mom) * (double)rv);
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward scan
+// ------------------------------------------------------------------------------------------
+template <int NEURON, int VEC, bool SAVE>
+__global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
+    const float* __restrict__ y, int64_t ldy, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const float* __restrict__ v0, const float* __restrict__ i0, float* __restrict__ out, int64_t ldo,
+    float* __restrict__ vT, float* __restrict__ iT, float* __restrict__ vdec, int T, int64_t M, int C,
+    snn_neuron_params p) {
+    typedef typename Vec<VEC>::type V;
+    const int cv = C / VEC;
+    const int64_t total = M * cv;
+    for (int64_t col = (int64_t)blockIdx.x * kThreads + threadIdx.x; col < total;
+         col += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = col / cv;
+        const int c = (int)(col % cv) * VEC;
+        V v, i;
+        if (NEURON != SNN_NEURON_NONE) {
+            if (v0) v = Vec<VEC>::load(v0 + m * C + c);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lane<VEC>(v, j) = p.v_leak;
+            }
+            if (i0) i = Vec<VEC>::load(i0 + m * C + c);
+            else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lane<VEC>(i, j) = 0.0f;
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            const int64_t row = (int64_t)t * M + m;
+            V x = Vec<VEC>::load(y + row * ldy + c);
+            if (alpha) {
+                V a = Vec<VEC>::load(alpha + (int64_t)t * C + c);
+                V b = Vec<VEC>::load(beta + (int64_t)t * C + c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lane<VEC>(x, j) = lane<VEC>(x, j) * lane<VEC>(a, j) + lane<VEC>(b, j);
+            }
+            V o, vd;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float xj = lane<VEC>(x, j);
+                if (NEURON == SNN_NEURON_NONE) {
+                    lane<VEC>(o, j) = xj;
+                } else {
+                    float vj = lane<VEC>(v, j), ij = lane<VEC>(i, j);
+                    float i_new = ij + xj;
+                    float dv = p.c_mem * ((p.v_leak - vj) + i_new);
+                    float v_dec = vj + dv;
+                    float di = p.c_syn * i_new;
+                    lane<VEC>(i, j) = i_new + di;
+                    if (NEURON == SNN_NEURON_LIF) {
+                        float u = v_dec - p.v_th;
+                        float z = (u > 0.0f) ? 1.0f : 0.0f;
+                        lane<VEC>(v, j) = (1.0f - z) * v_dec + z * p.v_reset;
+                        lane<VEC>(o, j) = z;
+                        lane<VEC>(vd, j) = v_dec;
+                    } else {
+                        lane<VEC>(v, j) = v_dec;
+                        lane<VEC>(o, j) = (NEURON == SNN_NEURON_LI_TANH) ? tanhf(v_dec) : v_dec;
+                    }
+                }
+            }
+            Vec<VEC>::store(out + row * ldo + c, o);
+            if (SAVE && NEURON == SNN_NEURON_LIF) Vec<VEC>::store(vdec + row * C + c, vd);
+        }
+        if (NEURON != SNN_NEURON_NONE) {
+            if (vT) Vec<VEC>::store(vT + m * C + c, v);
+            if (iT) Vec<VEC>::store(iT + m * C + c, i);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward (reverse-time) scan with per-(t,c) partial sums for the BatchNorm backward.
+// grid = (GX pixel groups, GY channel blocks).  LDS holds red[T][cb][2] fp32 block sums.
+// ------------------------------------------------------------------------------------------
+struct BwdPlan {
+    int vec, cvb, gy, gx;
+    size_t lds_bytes;
+};
+
+static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
+    BwdPlan pl;
+    pl.vec = (C % 4 == 0) ? 4 : 1;
+    int cv = C / pl.vec;
+    int cvb = cv < kThreads ? cv : kThreads;
+    if (with_sums) {
+        // LDS budget 64 KiB: T * cb * 2 floats
+        int64_t max_cb = (64 * 1024) / ((int64_t)T * 8);
+        int max_cvb = (int)(max_cb / pl.vec);
+        if (max_cvb < 1) max_cvb = 1;
+        if (cvb > max_cvb) cvb = max_cvb;
+    }
+    pl.cvb = cvb;
+    pl.gy = (int)snn_ceil_div(cv, cvb);
+    int P = kThreads / cvb;
+    int64_t gx = snn_ceil_div(M, (int64_t)P);
+    int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;
+    cap = cap / pl.gy;
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    pl.gx = (int)gx;
+    pl.lds_bytes = with_sums ? (size_t)T * cvb * pl.vec * 2 * sizeof(float) : 0;
+    return pl;
+}
+
+template <int NEURON, int VEC>
+__global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
+    const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
+    int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ scale,
+    float* __restrict__ gx, float* __restrict__ g_v0, float* __restrict__ g_i0, double* __restrict__ sums, int T,
+    int64_t M, int C, int cvb, snn_neuron_params p) {
+    typedef typename Vec<VEC>::type V;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [T][cvb*VEC][2]
+    const int cv = C / VEC;
+    const int P = kThreads / cvb;
+    const int tid = threadIdx.x;
+    const int cgl = tid % cvb, ps = tid / cvb;
+    const int cg = blockIdx.y * cvb + cgl;
+    const int cb = cvb * VEC;
+    const bool active = (ps < P) && (cg < cv);
+    const int c = cg * VEC;
+    if (sums) {
+        for (int k = tid; k < T * cb * 2; k += kThreads) red[k] = 0.0f;
+        __syncthreads();
+    }
+    if (active) {
+        const float one_m_cmem = 1.0f - p.c_mem;
+        const float one_p_csyn = 1.0f + p.c_syn;
+        for (int64_t m = (int64_t)blockIdx.x * P + ps; m < M; m += (int64_t)gridDim.x * P) {
+            V gv, gi;
+            if (NEURON != SNN_NEURON_NONE) {
+                if (g_vT) gv = Vec<VEC>::load(g_vT + m * C + c);
+                else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) lane<VEC>(gv, j) = 0.0f;
+                }
+                if (g_iT) gi = Vec<VEC>::load(g_iT + m * C + c);
+                else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) lane<VEC>(gi, j) = 0.0f;
+                }
+            }
+            for (int t = T - 1; t >= 0; --t) {
+                const int64_t row = (int64_t)t * M + m;
+                V go = Vec<VEC>::load(g_out + row * ldg + c);
+                V st;
+                if (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH) st = Vec<VEC>::load(state + row * C + c);
+                V g;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float goj = lane<VEC>(go, j);
+                    if (NEURON == SNN_NEURON_NONE) {
+                        lane<VEC>(g, j) = goj;
+                    } else if (NEURON == SNN_NEURON_LIF) {
+                        float vd = lane<VEC>(st, j);
+                        float u = vd - p.v_th;
+                        float z = (u > 0.0f) ? 1.0f : 0.0f;
+                        float den = p.alpha * fabsf(u) + 1.0f;
+                        float sg = 1.0f / (den * den);
+                        float gvj = lane<VEC>(gv, j);
+                        float gz = goj + gvj * (p.v_reset - vd);
+                        float g_vd = gvj * (1.0f - z) + gz * sg;
+                        float g_in = p.c_mem * g_vd + lane<VEC>(gi, j) * one_p_csyn;
+                        lane<VEC>(gv, j) = g_vd * one_m_cmem;
+                        lane<VEC>(gi, j) = g_in;
+                        lane<VEC>(g, j) = g_in;
+                    } else {
+                        float d = 1.0f;
+                        if (NEURON == SNN_NEURON_LI_TANH) {
+                            float o = lane<VEC>(st, j);
+                            d = 1.0f - o * o;
+                        }
+                        float g_vn = goj * d + lane<VEC>(gv, j);
+                        float g_in = p.c_mem * g_vn + lane<VEC>(gi, j) * one_p_csyn;
+                        lane<VEC>(gv, j) = g_vn * one_m_cmem;
+                        lane<VEC>(gi, j) = g_in;
+                        lane<VEC>(g, j) = g_in;
+                    }
+                }
+                if (sums) {
+                    V yv = Vec<VEC>::load(y + row * ldy + c);
+                    float* r = red + ((int64_t)t * cb + cgl * VEC) * 2;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        atomicAdd(r + j * 2 + 0, lane<VEC>(g, j));
+                        atomicAdd(r + j * 2 + 1, lane<VEC>(g, j) * lane<VEC>(yv, j));
+                    }
+                }
+                if (scale) {
+                    V sc = Vec<VEC>::load(scale + (int64_t)t * C + c);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
+                }
+                Vec<VEC>::store(gx + row * C + c, g);
+            }
+            if (NEURON != SNN_NEURON_NONE) {
+                if (g_v0) Vec<VEC>::store(g_v0 + m * C + c, gv);
+                if (g_i0) Vec<VEC>::store(g_i0 + m * C + c, gi);
+            }
+        }
+    }
+    if (sums) {
+        __syncthreads();
+        // sums[bx][t][c][2]
+        double* dst = sums + (int64_t)blockIdx.x * T * C * 2;
+        const int c_lo = blockIdx.y * cb;
+        for (int k = tid; k < T * cb; k += kThreads) {
+            int t = k / cb, cl = k % cb;
+            if (c_lo + cl < C) {
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = (double)red[k * 2 + 0];
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = (double)red[k * 2 + 1];
+            }
+        }
+    }
+}
+
+// reduce block partials -> per (t,c) S1 = sum gx, S2 = sum gx*y (kept in block 0's slot), emit coefficients
+__global__ void k_bn_bwd_finalize(double* __restrict__ sums, int gx_blocks, int T, int64_t M, int C,
+                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, float* __restrict__ coefA,
+                                  float* __restrict__ coefB, float* __restrict__ coefC) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * C) return;
+    int c = idx % C;
+    double s1 = 0.0, sy = 0.0;
+    for (int b = 0; b < gx_blocks; ++b) {
+        const double* src = sums + ((int64_t)b * T * C + idx) * 2;
+        s1 += src[0];
+        sy += src[1];
+    }
+    double mu = (double)mean[idx], is = (double)invstd[idx];
+    double s2 = is * (sy - mu * s1);  // sum gx * xhat
+    sums[(int64_t)idx * 2 + 0] = s1;
+    sums[(int64_t)idx * 2 + 1] = s2;
+    double n = (double)M;
+    double a = (double)(gamma ? gamma[c] : 1.0f) * is;
+    double m1 = s1 / n, m2 = s2 / n;
+    coefA[idx] = (float)a;
+    coefB[idx] = (float)(-a * is * m2);
+    coefC[idx] = (float)(-a * m1 + a * is * mu * m2);
+}
+
+__global__ void k_bn_bwd_params(const double* __restrict__ sums, int T, int C, float* __restrict__ dgamma,
+                                float* __restrict__ dbias, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int t = 0; t < T; ++t) {
+        db += sums[((int64_t)t * C + c) * 2 + 0];
+        dg += sums[((int64_t)t * C + c) * 2 + 1];
+    }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+    if (dbias) dbias[c] = accumulate ? dbias[c] + (float)db : (float)db;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restrict__ gx, const float* __restrict__ y,
+                                                           int64_t ldy, const float* __restrict__ coefA,
+                                                           const float* __restrict__ coefB,
+                                                           const float* __restrict__ coefC, float* __restrict__ dy,
+                                                           int64_t lddy, int T, int64_t M, int C, int accumulate) {
+    typedef typename Vec<VEC>::type V;
+    const int cv = C / VEC;
+    const int64_t total = (int64_t)T * M * cv;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t row = e / cv;
+        const int c = (int)(e % cv) * VEC;
+        const int64_t t = row / M;
+        V g = Vec<VEC>::load(gx + row * C + c);
+        V yv = Vec<VEC>::load(y + row * ldy + c);
+        V a = Vec<VEC>::load(coefA + t * C + c);
+        V b = Vec<VEC>::load(coefB + t * C + c);
+        V k = Vec<VEC>::load(coefC + t * C + c);
+        V r;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            lane<VEC>(r, j) = lane<VEC>(a, j) * lane<VEC>(g, j) + lane<VEC>(b, j) * lane<VEC>(yv, j) + lane<VEC>(k, j);
+        float* d = dy + row * lddy + c;
+        if (accumulate) {
+            V old = Vec<VEC>::load(d);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) lane<VEC>(r, j) += lane<VEC>(old, j);
+        }
+        Vec<VEC>::store(d, r);
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------- C ABI
+extern "C" size_t snn_bn_stats_partial_size(int T, int64_t M, int C) {
+    if (T <= 0 || M <= 0 || C <= 0) return 0;
+    StatsPlan pl = stats_plan(T, M, C);
+    // partial sums followed by T*C unbiased variances (scratch of the finalize step)
+    return (size_t)T * pl.chunks * C * 2 + (size_t)T * C;
+}
+
+extern "C" int snn_bn_stats(const float* y, int64_t ldy, int T, int64_t M, int C, double* partial, void* stream) {
+    SNN_REQUIRE(y && partial, "snn_bn_stats: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C, "snn_bn_stats: bad shape T=%d M=%lld C=%d ldy=%lld", T,
+                (long long)M, C, (long long)ldy);
+    StatsPlan pl = stats_plan(T, M, C);
+    if (pl.vec == 4) SNN_REQUIRE(aligned16(y) && ldy % 4 == 0, "snn_bn_stats: y must be 16-byte aligned with ldy%%4==0");
+    dim3 grid(pl.chunks, T, pl.zblocks);
+    if (pl.vec == 4)
+        hipLaunchKernelGGL(k_bn_stats<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, y, ldy, M, C, pl.cvb, partial);
+    else
+        hipLaunchKernelGGL(k_bn_stats<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, y, ldy, M, C, pl.cvb, partial);
+    SNN_CHECK_LAUNCH("snn_bn_stats");
+    return 0;
+}
+
+extern "C" int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C, const float* gamma,
+                                     const float* bias, float eps, float momentum, float* running_mean,
+                                     float* running_var, int use_running, float* mean, float* invstd, float* alpha,
+                                     float* beta, void* stream) {
+    SNN_REQUIRE(mean && invstd && alpha && beta, "snn_bn_stats_finalize: null output");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_stats_finalize: bad shape");
+    SNN_REQUIRE(use_running ? (running_mean && running_var) : (partial != nullptr),
+                "snn_bn_stats_finalize: missing statistics source");
+    StatsPlan pl = stats_plan(T, M, C);
+    double* var_unbiased =
+        use_running ? nullptr : const_cast<double*>(partial) + (size_t)T * pl.chunks * C * 2;
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_stats_finalize, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                       pl.chunks, T, M, C, gamma, bias, eps, running_mean, running_var, use_running, mean, invstd,
+                       alpha, beta, var_unbiased);
+    SNN_CHECK_LAUNCH("snn_bn_stats_finalize");
+    if (!use_running && running_mean && running_var) {
+        hipLaunchKernelGGL(k_bn_running_update, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean,
+                           var_unbiased, T, C, momentum, running_mean, running_var);
+        SNN_CHECK_LAUNCH("snn_bn_running_update");
+    }
+    return 0;
+}
+
+#define SNN_DISPATCH_FWD(NEURON, SAVE)                                                                            \
+    do {                                                                                                          \
+        if (vec == 4)                                                                                             \
+            hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 4, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, vT, iT, vdec, T, M, C, *p);                  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 1, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, vT, iT, vdec, T, M, C, *p);                  \
+    } while (0)
+
+extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta,
+                                     const float* v0, const float* i0, float* out, int64_t ldo, float* vT, float* iT,
+                                     float* vdec, int T, int64_t M, int C, const snn_neuron_params* p, void* stream) {
+    SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && ldo >= C, "snn_affine_neuron_fwd: bad shape");
+    SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_affine_neuron_fwd: alpha/beta must come together");
+    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_LI_TANH, "snn_affine_neuron_fwd: bad neuron %d",
+                neuron);
+    int vec = (C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out) && aligned16(alpha) &&
+               aligned16(beta) && aligned16(v0) && aligned16(i0) && aligned16(vT) && aligned16(iT) && aligned16(vdec))
+                  ? 4
+                  : 1;
+    int64_t total = M * (C / vec);
+    int64_t blocks = snn_ceil_div(total, kThreads);
+    if (blocks > SNN_MAX_BLOCKS) blocks = SNN_MAX_BLOCKS;
+    dim3 grid((unsigned)blocks);
+    switch (neuron) {
+        case SNN_NEURON_NONE: SNN_DISPATCH_FWD(SNN_NEURON_NONE, false); break;
+        case SNN_NEURON_LIF:
+            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_LIF, true);
+            else SNN_DISPATCH_FWD(SNN_NEURON_LIF, false);
+            break;
+        case SNN_NEURON_LI: SNN_DISPATCH_FWD(SNN_NEURON_LI, false); break;
+        default: SNN_DISPATCH_FWD(SNN_NEURON_LI_TANH, false); break;
+    }
+    SNN_CHECK_LAUNCH("snn_affine_neuron_fwd");
+    return 0;
+}
+
+extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
+    if (T <= 0 || M <= 0 || C <= 0) return 0;
+    BwdPlan pl = bwd_plan(T, M, C, true);
+    return (size_t)pl.gx * T * C * 2;
+}
+
+#define SNN_DISPATCH_BWD(NEURON)                                                                                   \
+    do {                                                                                                           \
+        if (pl.vec == 4)                                                                                           \
+            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 4>), grid, dim3(kThreads), pl.lds_bytes,                \
+                               (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0,   \
+                               sums, T, M, C, pl.cvb, *p);                                                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 1>), grid, dim3(kThreads), pl.lds_bytes,                \
+                               (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0,   \
+                               sums, T, M, C, pl.cvb, *p);                                                          \
+    } while (0)
+
+extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state, const float* y,
+                                     int64_t ldy, const float* g_vT, const float* g_iT, const float* scale, float* gx,
+                                     float* g_v0, float* g_i0, double* sums, int T, int64_t M, int C,
+                                     const snn_neuron_params* p, void* stream) {
+    SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
+    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_LI_TANH, "snn_affine_neuron_bwd: bad neuron %d",
+                neuron);
+    SNN_REQUIRE(!(neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI_TANH) || state,
+                "snn_affine_neuron_bwd: saved state required");
+    SNN_REQUIRE(!sums || (y && ldy >= C), "snn_affine_neuron_bwd: y required for the BatchNorm sums");
+    BwdPlan pl = bwd_plan(T, M, C, sums != nullptr);
+    if (pl.vec == 4) {
+        bool ok = ldg % 4 == 0 && aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) &&
+                  aligned16(scale) && aligned16(gx) && aligned16(g_v0) && aligned16(g_i0) &&
+                  (!sums || (ldy % 4 == 0 && aligned16(y)));
+        SNN_REQUIRE(ok, "snn_affine_neuron_bwd: buffers must be 16-byte aligned when C%%4==0");
+    }
+    dim3 grid(pl.gx, pl.gy);
+    switch (neuron) {
+        case SNN_NEURON_NONE: SNN_DISPATCH_BWD(SNN_NEURON_NONE); break;
+        case SNN_NEURON_LIF: SNN_DISPATCH_BWD(SNN_NEURON_LIF); break;
+        case SNN_NEURON_LI: SNN_DISPATCH_BWD(SNN_NEURON_LI); break;
+        default: SNN_DISPATCH_BWD(SNN_NEURON_LI_TANH); break;
+    }
+    SNN_CHECK_LAUNCH("snn_affine_neuron_bwd");
+    return 0;
+}
+
+extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const float* gamma, const float* mean,
+                                   const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                   float* dbias, int accumulate, void* stream) {
+    SNN_REQUIRE(sums && mean && invstd && coefA && coefB && coefC, "snn_bn_bwd_finalize: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_bwd_finalize: bad shape");
+    BwdPlan pl = bwd_plan(T, M, C, true);
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, M,
+                       C, gamma, mean, invstd, coefA, coefB, coefC);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_finalize");
+    if (dgamma || dbias) {
+        hipLaunchKernelGGL(k_bn_bwd_params, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, T, C,
+                           dgamma, dbias, accumulate);
+        SNN_CHECK_LAUNCH("snn_bn_bwd_params");
+    }
+    return 0;
+}
+
+extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, const float* coefA, const float* coefB,
+                                const float* coefC, float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate,
+                                void* stream) {
+    SNN_REQUIRE(gx && y && coefA && coefB && coefC && dy, "snn_bn_bwd_apply: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && lddy >= C, "snn_bn_bwd_apply: bad shape");
+    int vec = (C % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && aligned16(gx) && aligned16(y) && aligned16(dy) &&
+               aligned16(coefA) && aligned16(coefB) && aligned16(coefC))
+                  ? 4
+                  : 1;
+    int64_t total = (int64_t)T * M * (C / vec);
+    int64_t blocks = snn_ceil_div(total, kThreads);
+    if (blocks > SNN_MAX_BLOCKS) blocks = SNN_MAX_BLOCKS;
+    if (vec == 4)
+        hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y,
+                           ldy, coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y,
+                           ldy, coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_apply");
+    return 0;
+}

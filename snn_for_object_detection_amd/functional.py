@@ -1,0 +1,515 @@
+"""Autograd operators over the HIP C ABI (``include/snn_hip.h``).
+
+Every operator works on a whole layer-major sequence ``[T, B, C, H, W]`` (logical NCHW per
+frame, channels-last memory ``[T][B][H][W][C]``), or on one timestep ``[B, C, H, W]`` which is
+the ``T = 1`` case of the same kernels (streaming ``predict``, reference-style time-outer loops).
+
+torch is used for device memory, the autograd tape and the current stream only; all arithmetic
+of the hot path happens in ``libsnn_hip.so``.  No CPU / eager fallback exists: tensors that are
+not on a HIP device raise.
+"""
+
+from typing import List, NamedTuple, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import NeuronParams
+
+# norse defaults as fp32 rounds them (dt*tau_mem_inv, -dt*tau_syn_inv, v_leak, v_th, v_reset, alpha);
+# oracle/neurons.py:neuron_constants() evaluates the same torch expressions (tests pin the equality).
+_F32 = torch.float32
+DEFAULT_DT = 0.001
+
+
+def neuron_params(dt: float = DEFAULT_DT) -> NeuronParams:
+    tau_syn_inv = torch.as_tensor(1.0 / 5e-3)
+    tau_mem_inv = torch.as_tensor(1.0 / 1e-2)
+    return NeuronParams((dt * tau_mem_inv).item(), (-dt * tau_syn_inv).item(), 0.0, 1.0, 0.0, 100.0)
+
+
+# ------------------------------------------------------------------------------------------- helpers
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the MI355X path has no CPU fallback "
+                           "(move the model and its inputs to a HIP device)")
+    if t.dtype != _F32:
+        raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
+
+
+def is_channels_last(x: torch.Tensor) -> bool:
+    """True when the logical ``[..., C, H, W]`` tensor is stored densely as ``[..., H, W, C]``."""
+    nd = x.dim()
+    perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
+    return x.permute(perm).is_contiguous()
+
+
+def _cl_view(buf: torch.Tensor) -> torch.Tensor:
+    """dense ``[..., H, W, C]`` buffer -> logical ``[..., C, H, W]`` view."""
+    nd = buf.dim()
+    return buf.permute(list(range(nd - 3)) + [nd - 1, nd - 3, nd - 2])
+
+
+def _new_cl(lead: Sequence[int], C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+    return _cl_view(torch.empty((*lead, H, W, C), device=like.device, dtype=_F32))
+
+
+def _raw_to_cl(x: torch.Tensor) -> torch.Tensor:
+    """Non-differentiable layout change to channels-last memory (same logical shape)."""
+    if is_channels_last(x):
+        return x
+    _require_device(x, "layout")
+    xc = x.contiguous()
+    lead, (C, H, W) = xc.shape[:-3], xc.shape[-3:]
+    n = 1
+    for d in lead:
+        n *= d
+    out = _new_cl(lead, C, H, W, xc)
+    _hip.call("snn_nchw_to_nhwc", xc.data_ptr(), out.data_ptr(), n, C, H, W, _stream())
+    return out
+
+
+def _raw_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    if x.is_contiguous():
+        return x
+    x = _raw_to_cl(x)
+    lead, (C, H, W) = x.shape[:-3], x.shape[-3:]
+    n = 1
+    for d in lead:
+        n *= d
+    out = torch.empty(x.shape, device=x.device, dtype=_F32)
+    _hip.call("snn_nhwc_to_nchw", x.data_ptr(), out.data_ptr(), n, C, H, W, _stream())
+    return out
+
+
+class _ToChannelsLast(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _raw_to_cl(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _raw_to_nchw(g)
+
+
+def to_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """Differentiable entry adapter for callers holding NCHW-contiguous frames (soda.py:138-144)."""
+    if is_channels_last(x):
+        return x
+    return _ToChannelsLast.apply(x)
+
+
+def as_sequence(x: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+    """``[B,C,H,W]`` or ``[T,B,C,H,W]`` -> channels-last ``[T,B,C,H,W]`` and "was a single step"."""
+    if x.dim() == 4:
+        return to_channels_last(x).unsqueeze(0), True
+    if x.dim() == 5:
+        return to_channels_last(x), False
+    raise RuntimeError(f"expected [B,C,H,W] or [T,B,C,H,W], got shape {tuple(x.shape)}")
+
+
+def _dims5(x: torch.Tensor):
+    T, B, C, H, W = x.shape
+    return T, B, C, H, W
+
+
+# ------------------------------------------------------------------------------------------- conv
+class _Conv2d(Function):
+    """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride: int, pad: int):
+        _require_device(x, "conv2d input")
+        _require_device(weight, "conv2d weight")
+        T, B, Cin, H, W = _dims5(x)
+        Cout, Cin_w, KH, KW = weight.shape
+        if Cin_w != Cin:
+            raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_w}")
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        x = _raw_to_cl(x)
+        w = weight.detach()
+        w_ohwi = w if is_channels_last(w) else _raw_to_cl(w)
+        y = _new_cl((T, B), Cout, Ho, Wo, x)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w_ohwi.data_ptr(), y.data_ptr(), Cout, T * B, H, W, Cin,
+                  Ho, Wo, Cout, KH, KW, stride, pad, 0, _stream())
+        ctx.save_for_backward(x, w_ohwi)
+        ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_ohwi = ctx.saved_tensors
+        T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = ctx.geom
+        gy = _raw_to_cl(gy)
+        st = _stream()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
+            _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
+            dx = _new_cl((T, B), Cin, H, W, x)
+            _hip.call("snn_conv2d_dgrad", gy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
+                      Ho, Wo, Cout, KH, KW, stride, pad, 0, st)
+        if ctx.needs_input_grad[1]:
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
+            ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
+            dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
+            _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, dw_ohwi.data_ptr(), T * B, H, W,
+                      Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
+            dw = dw_ohwi.permute(0, 3, 1, 2)
+        return dx, dw, None, None
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
+    seq, single = as_sequence(x)
+    y = _Conv2d.apply(seq, weight, int(stride), int(padding))
+    return y[0] if single else y
+
+
+# ------------------------------------------------------------------------------------------- norm + neuron
+class NeuronState(NamedTuple):
+    """State of a LIF / LI layer: membrane potential and synaptic current, each ``[B,C,h,w]``.
+
+    Same field names / order as norse's ``LIFFeedForwardState`` and ``LIState``.
+    """
+    v: torch.Tensor
+    i: torch.Tensor
+
+
+class _AffineNeuron(Function):
+    """[BatchNorm2d (per-timestep batch statistics)] -> [LIF | LI | LI+Tanh | nothing], fused.
+
+    inputs : y[T,B,C,H,W], gamma[C]|None, bias[C]|None, v0|None, i0|None, + non-tensor config
+    outputs: out[T,B,C,H,W], vT[B,C,H,W], iT[B,C,H,W]  (vT/iT are dummies when neuron == NONE)
+    """
+
+    @staticmethod
+    def forward(ctx, y, gamma, bias, v0, i0, cfg):
+        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params) = cfg
+        _require_device(y, "norm/neuron input")
+        y = _raw_to_cl(y)
+        T, B, C, H, W = _dims5(y)
+        M = B * H * W
+        st = _stream()
+        dev = y.device
+        alpha = beta = mean = invstd = None
+        use_running = has_bn and not training
+        if has_bn:
+            mean = torch.empty((T, C), device=dev, dtype=_F32)
+            invstd = torch.empty((T, C), device=dev, dtype=_F32)
+            alpha = torch.empty((T, C), device=dev, dtype=_F32)
+            beta = torch.empty((T, C), device=dev, dtype=_F32)
+            g_ptr = _ptr(gamma.detach()) if gamma is not None else None
+            b_ptr = _ptr(bias.detach()) if bias is not None else None
+            if use_running:
+                if running_mean is None or running_var is None:
+                    raise RuntimeError("BatchNorm in eval mode needs running statistics")
+                _hip.call("snn_bn_stats_finalize", None, T, M, C, g_ptr, b_ptr, eps, momentum,
+                          running_mean.data_ptr(), running_var.data_ptr(), 1, mean.data_ptr(), invstd.data_ptr(),
+                          alpha.data_ptr(), beta.data_ptr(), st)
+            else:
+                n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
+                partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
+                _hip.call("snn_bn_stats", y.data_ptr(), C, T, M, C, partial.data_ptr(), st)
+                _hip.call("snn_bn_stats_finalize", partial.data_ptr(), T, M, C, g_ptr, b_ptr, eps, momentum,
+                          _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
+                          alpha.data_ptr(), beta.data_ptr(), st)
+        out = _new_cl((T, B), C, H, W, y)
+        has_state = neuron != _hip.NEURON_NONE
+        vT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
+        iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
+        need_grad = any(ctx.needs_input_grad[:5])
+        vdec = None
+        if neuron == _hip.NEURON_LIF and need_grad:
+            vdec = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
+        if v0 is not None:
+            v0 = _expand_state(v0, (B, C, H, W), dev)
+        if i0 is not None:
+            i0 = _expand_state(i0, (B, C, H, W), dev)
+        _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), C, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
+                  out.data_ptr(), C, _ptr(vT) if has_state else None, _ptr(iT) if has_state else None, _ptr(vdec),
+                  T, M, C, params, st)
+        ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
+        ctx.has_v0 = v0 is not None
+        ctx.has_i0 = i0 is not None
+        state = vdec if neuron == _hip.NEURON_LIF else (out if neuron == _hip.NEURON_LI_TANH else None)
+        ctx.save_for_backward(y, gamma, mean, invstd, alpha, state)
+        if not has_state:
+            ctx.mark_non_differentiable(vT, iT)
+        # with a neuron, vT / iT stay differentiable (time-outer BPTT through the carried state)
+        return out, vT, iT
+
+    @staticmethod
+    def backward(ctx, g_out, g_vT, g_iT):
+        y, gamma, mean, invstd, alpha, state = ctx.saved_tensors
+        neuron, has_bn, use_running, params, (T, B, C, H, W) = ctx.cfg
+        M = B * H * W
+        st = _stream()
+        dev = y.device
+        has_state = neuron != _hip.NEURON_NONE
+        if g_out is None:
+            g_out = torch.zeros((T, B, H, W, C), device=dev, dtype=_F32)
+            g_out = _cl_view(g_out)
+        g_out = _raw_to_cl(g_out)
+        if not has_state:
+            g_vT = g_iT = None
+        if g_vT is not None:
+            g_vT = _raw_to_cl(g_vT)
+        if g_iT is not None:
+            g_iT = _raw_to_cl(g_iT)
+        need_y = ctx.needs_input_grad[0]
+        need_gamma = has_bn and gamma is not None and ctx.needs_input_grad[1]
+        need_bias = has_bn and ctx.needs_input_grad[2]
+        need_sums = has_bn and ((need_y and not use_running) or need_gamma or need_bias)
+        gx = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
+        g_v0 = _new_cl((B,), C, H, W, y) if (has_state and ctx.has_v0 and ctx.needs_input_grad[3]) else None
+        g_i0 = _new_cl((B,), C, H, W, y) if (has_state and ctx.has_i0 and ctx.needs_input_grad[4]) else None
+        sums = None
+        if need_sums:
+            n_sums = _hip.query("snn_affine_neuron_bwd_sums_size", T, M, C)
+            sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
+        # eval-mode BN has no batch coupling: dy = alpha * gx, applied while gx is written
+        scale = alpha if (has_bn and use_running) else None
+        _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), C, _ptr(state), y.data_ptr(), C, _ptr(g_vT),
+                  _ptr(g_iT), _ptr(scale), gx.data_ptr(), _ptr(g_v0), _ptr(g_i0), _ptr(sums), T, M, C, params, st)
+        dy = dgamma = dbias = None
+        if need_sums:
+            coef = torch.empty((3, T, C), device=dev, dtype=_F32)
+            dgamma = torch.empty((C,), device=dev, dtype=_F32) if need_gamma else None
+            dbias = torch.empty((C,), device=dev, dtype=_F32) if need_bias else None
+            _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
+                      invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), _ptr(dgamma),
+                      _ptr(dbias), 0, st)
+            if need_y and not use_running:
+                # in place: dy overwrites gx
+                _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), C, coef[0].data_ptr(), coef[1].data_ptr(),
+                          coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
+        if need_y:
+            dy = _cl_view(gx)
+        return dy, dgamma, dbias, g_v0, g_i0, None
+
+
+def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
+    """State tensors may be 0-dim (LICell's initial v) or NCHW; the kernel wants dense [B,H,W,C]."""
+    s = s.detach()
+    if s.dim() == 0 or tuple(s.shape) != tuple(shape):
+        s = s.to(device=dev, dtype=_F32).expand(shape)
+    return _raw_to_cl(s)
+
+
+def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = None, bn=None,
+                  params: Optional[NeuronParams] = None):
+    """Fused ``[Norm] -> [neuron]`` over a sequence or a single step.
+
+    ``bn`` is an ``nn.BatchNorm2d``-like module (weight, bias, running stats, eps, momentum, training)
+    or None.  Returns ``(out, NeuronState | None)``.
+    """
+    seq, single = as_sequence(y)
+    params = params or neuron_params()
+    has_bn = bn is not None
+    gamma = bias = rm = rv = None
+    training, eps, momentum = False, 1e-5, 0.1
+    if has_bn:
+        gamma, bias = bn.weight, bn.bias
+        training = bn.training or (bn.running_mean is None and bn.running_var is None)
+        rm, rv = bn.running_mean, bn.running_var
+        eps = bn.eps
+        if bn.momentum is None:
+            raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
+        momentum = bn.momentum
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(seq.shape[0])
+    v0 = i0 = None
+    if state is not None:
+        v0, i0 = state
+    cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params)
+    out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
+    new_state = NeuronState(vT, iT) if neuron != _hip.NEURON_NONE else None
+    return (out[0] if single else out), new_state
+
+
+# ------------------------------------------------------------------------------------------- merges
+class _Concat(Function):
+    """Dense merge: torch.cat(out, dim=1) per timestep (generator.py:157-158)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_raw_to_cl(x) for x in xs]
+        T, B, _, H, W = _dims5(xs[0])
+        widths = [x.shape[2] for x in xs]
+        Ct = sum(widths)
+        out = _new_cl((T, B), Ct, H, W, xs[0])
+        M, st, off = T * B * H * W, _stream(), 0
+        for x, c in zip(xs, widths):
+            _require_device(x, "concat input")
+            if x.shape[0] != T or x.shape[1] != B or x.shape[3] != H or x.shape[4] != W:
+                raise RuntimeError("Dense merge: branch outputs differ in shape")
+            _hip.call("snn_copy_channels", x.data_ptr(), c, out.data_ptr() + 4 * off, Ct, M, c, st)
+            off += c
+        ctx.widths = widths
+        ctx.shape = (T, B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _raw_to_cl(g)
+        T, B, H, W = ctx.shape
+        Ct = sum(ctx.widths)
+        M, st, off = T * B * H * W, _stream(), 0
+        grads = []
+        for k, c in enumerate(ctx.widths):
+            if ctx.needs_input_grad[k]:
+                gk = _new_cl((T, B), c, H, W, g)
+                _hip.call("snn_copy_channels", g.data_ptr() + 4 * off, Ct, gk.data_ptr(), c, M, c, st)
+                grads.append(gk)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+class _Sum(Function):
+    """Residual merge: torch.stack(out).sum(0) (generator.py:145-146)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_raw_to_cl(x) for x in xs]
+        for x in xs:
+            _require_device(x, "residual input")
+            if x.shape != xs[0].shape:
+                raise RuntimeError("Residual merge: branch outputs differ in shape")
+        T, B, C, H, W = _dims5(xs[0])
+        out = _new_cl((T, B), C, H, W, xs[0])
+        n, st = xs[0].numel(), _stream()
+        _hip.call("snn_add", xs[0].data_ptr(), xs[1].data_ptr(), out.data_ptr(), n, st)
+        for x in xs[2:]:
+            _hip.call("snn_add", out.data_ptr(), x.data_ptr(), out.data_ptr(), n, st)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g if need else None for need in ctx.needs_input_grad)
+
+
+def concat_channels(xs: List[torch.Tensor]) -> torch.Tensor:
+    if len(xs) == 1:
+        return xs[0]
+    seqs = [as_sequence(x) for x in xs]
+    out = _Concat.apply(*[s for s, _ in seqs])
+    return out[0] if seqs[0][1] else out
+
+
+def sum_tensors(xs: List[torch.Tensor]) -> torch.Tensor:
+    if len(xs) == 1:
+        return xs[0]
+    seqs = [as_sequence(x) for x in xs]
+    out = _Sum.apply(*[s for s, _ in seqs])
+    return out[0] if seqs[0][1] else out
+
+
+# ------------------------------------------------------------------------------------------- pointwise / pooling
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act: int):
+        _require_device(x, "activation input")
+        x = _raw_to_cl(x)
+        y = _cl_view(torch.empty(x.permute(0, 1, 3, 4, 2).shape, device=x.device, dtype=_F32))
+        _hip.call("snn_act_fwd", act, x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.act = act
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y = ctx.saved_tensors
+        gy = _raw_to_cl(gy)
+        gx = _cl_view(torch.empty(x.permute(0, 1, 3, 4, 2).shape, device=x.device, dtype=_F32))
+        _hip.call("snn_act_bwd", ctx.act, x.data_ptr(), y.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(),
+                  _stream())
+        return gx, None
+
+
+def activation(x: torch.Tensor, act: int) -> torch.Tensor:
+    seq, single = as_sequence(x)
+    y = _Act.apply(seq, act)
+    return y[0] if single else y
+
+
+class _Pool(Function):
+    @staticmethod
+    def forward(ctx, x, kind: int, k: int, stride: int):
+        _require_device(x, "pool input")
+        x = _raw_to_cl(x)
+        T, B, C, H, W = _dims5(x)
+        Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
+        if Ho <= 0 or Wo <= 0:
+            raise RuntimeError(f"pool: window {k} larger than input {H}x{W}")
+        y = _new_cl((T, B), C, Ho, Wo, x)
+        _hip.call("snn_pool_fwd", kind, x.data_ptr(), y.data_ptr(), T * B, H, W, C, Ho, Wo, k, stride, _stream())
+        ctx.geom = (kind, k, stride, T, B, C, H, W, Ho, Wo)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        kind, k, stride, T, B, C, H, W, Ho, Wo = ctx.geom
+        gy = _raw_to_cl(gy)
+        gx = _new_cl((T, B), C, H, W, x)
+        _hip.call("snn_pool_bwd", kind, x.data_ptr(), gy.data_ptr(), gx.data_ptr(), T * B, H, W, C, Ho, Wo, k, stride,
+                  _stream())
+        return gx, None, None, None
+
+
+def pool2d(x: torch.Tensor, kind: int, kernel_size: int, stride: int) -> torch.Tensor:
+    seq, single = as_sequence(x)
+    y = _Pool.apply(seq, kind, int(kernel_size), int(stride))
+    return y[0] if single else y
+
+
+class _Upsample(Function):
+    @staticmethod
+    def forward(ctx, x, scale: int):
+        _require_device(x, "upsample input")
+        x = _raw_to_cl(x)
+        T, B, C, H, W = _dims5(x)
+        y = _new_cl((T, B), C, H * scale, W * scale, x)
+        _hip.call("snn_upsample_fwd", x.data_ptr(), y.data_ptr(), T * B, H, W, C, scale, _stream())
+        ctx.geom = (scale, T, B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        scale, T, B, C, H, W = ctx.geom
+        gy = _raw_to_cl(gy)
+        gx = _new_cl((T, B), C, H, W, gy)
+        _hip.call("snn_upsample_bwd", gy.data_ptr(), gx.data_ptr(), T * B, H, W, C, scale, _stream())
+        return gx, None
+
+
+def upsample_nearest(x: torch.Tensor, scale: int) -> torch.Tensor:
+    seq, single = as_sequence(x)
+    y = _Upsample.apply(seq, int(scale))
+    return y[0] if single else y
+
+
+# ------------------------------------------------------------------------------------------- events
+def events_to_frames(t_bin: torch.Tensor, x: torch.Tensor, y: torch.Tensor, p: torch.Tensor, T: int, H: int,
+                     W: int) -> torch.Tensor:
+    """Scatter events into binary frames ``[T, 2, H, W]`` (utils/datasets.py:378-435), on device."""
+    for t in (t_bin, x, y, p):
+        if not t.is_cuda or t.dtype != torch.int32:
+            raise RuntimeError("events_to_frames: int32 HIP tensors required")
+    buf = torch.empty((T, H, W, 2), device=t_bin.device, dtype=_F32)
+    _hip.call("snn_events_to_frames", t_bin.data_ptr(), x.data_ptr(), y.data_ptr(), p.data_ptr(), t_bin.numel(),
+              buf.data_ptr(), T, H, W, _stream())
+    return buf.permute(0, 3, 1, 2)

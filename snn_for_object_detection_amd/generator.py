@@ -1,0 +1,319 @@
+"""Model generation tools (mirror of the reference's ``models/generator.py``).
+
+Same description API and module-tree layout (``BlockGen.net`` is a ``ModuleList`` of per-branch
+``ModuleList``s, ``generator.py:115,143``; heads are ``model_{i}.{base_net,box_net,cls_net}``,
+``:403-413,522-525``) so ``state_dict`` keys match the reference's checkpoints.
+
+What is re-designed is the EXECUTOR.  Every recurrence in the generated nets is per-neuron and a
+block is a DAG per timestep (``generator.py:181-198``), so instead of the reference's time-outer
+loop (``soda.py:141-144``) a block may be handed the whole sequence ``[T,B,C,H,W]`` and runs
+layer-major: one conv launch per layer for all ``T*B`` frames and one fused
+BatchNorm+LIF/LI temporal-scan launch per ``Norm -> neuron`` pair, with the membrane state kept in
+registers across ``T``.  A single timestep ``[B,C,H,W]`` (+ carried state) uses the same kernels
+with ``T = 1``, which keeps the reference's calling protocol for streaming ``predict``.
+
+``ListGen``  : ``List[LayerGen | ListGen]``;  ``ListState``: ``List[Tensor | None | ListState]``.
+"""
+
+import inspect
+from typing import Any, List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import _hip
+from . import functional as HF
+from .anchors import AnchorGenerator
+from .layer_gen import *  # noqa: F401,F403  (the reference re-exports the layer generators here)
+from .layer_gen import (Dense, HipBatchNorm2d, HipTanh, LayerGen, LICell, LIFCell, Residual, Return, StateStorage,
+                        Storage)
+
+ListGen = List[Union[LayerGen, "ListGen"]]
+ListState = List[Union[torch.Tensor, None, "ListState"]]
+
+
+def _is_module_stateful(m: nn.Module) -> bool:
+    """norse's rule (norse.torch.utils.state): a module is stateful iff ``forward`` takes ``state``."""
+    return "state" in inspect.signature(m.forward).parameters
+
+
+def _neuron_cell(layer: nn.Module) -> Optional[nn.Module]:
+    cell = layer.module if isinstance(layer, StateStorage) else layer
+    return cell if isinstance(cell, (LIFCell, LICell)) else None
+
+
+#####################################################################
+#                         Block Generators                          #
+#####################################################################
+class BlockGen(nn.Module):
+    """Builds a block from a (nested) configuration list and runs it (generator.py:35-198).
+
+    A plain list is one sequential branch; ``Residual([...])`` sums its branches, ``Dense([...])``
+    concatenates them on channels; nested lists become nested ``BlockGen``s.
+    """
+
+    def __init__(self, in_channels: int, cfgs: ListGen):
+        super().__init__()
+        self.out_channels = 0
+        if isinstance(cfgs, Residual):
+            self.merge = "residual"
+        elif isinstance(cfgs, Dense):
+            self.merge = "dense"
+        else:
+            self.merge = "forward"
+            cfgs = [cfgs]
+
+        branch_list: List[nn.ModuleList] = []
+        self.branch_state: List[List[bool]] = []
+        for branch_cfg in cfgs:
+            layers, flags, channels = self._make_branch(in_channels, branch_cfg)
+            branch_list.append(layers)
+            self.branch_state.append(flags)
+            self._account_channels(channels)
+        self.net = nn.ModuleList(branch_list)
+        # fused execution plan per branch: list of (kind, first_index, n_layers)
+        self._plan = [self._plan_branch(branch) for branch in self.net]
+
+    # ------------------------------------------------------------------ construction
+    def _make_branch(self, in_channels: int, cfg: ListGen) -> Tuple[nn.ModuleList, List[bool], int]:
+        state_layers: List[bool] = []
+        layer_list: List[nn.Module] = []
+        channels = in_channels
+        for layer_gen in cfg:
+            if isinstance(layer_gen, list):
+                layer = BlockGen(channels, layer_gen)
+                channels = layer.out_channels
+            else:
+                layer, channels = layer_gen.get(channels)
+            layer_list.append(layer)
+            state_layers.append(_is_module_stateful(layer))
+        return nn.ModuleList(layer_list), state_layers, channels
+
+    def _account_channels(self, channels: int) -> None:
+        if self.merge == "residual":
+            if not self.out_channels:
+                self.out_channels = channels
+            elif self.out_channels != channels:
+                raise RuntimeError(
+                    "[ERROR]: The number of channels in the residual "
+                    "network does not match! Check the configuration settings."
+                )
+        elif self.merge == "dense":
+            self.out_channels += channels
+        else:
+            self.out_channels = channels
+
+    @staticmethod
+    def _plan_branch(branch: nn.ModuleList) -> List[Tuple[str, int, int]]:
+        """Peephole fusion: Norm -> (LIF | LI [-> Tanh]) becomes one temporal-scan launch."""
+        plan, idx, n = [], 0, len(branch)
+        while idx < n:
+            layer = branch[idx]
+            nxt = branch[idx + 1] if idx + 1 < n else None
+            if isinstance(layer, HipBatchNorm2d) and nxt is not None and _neuron_cell(nxt) is not None:
+                cell = _neuron_cell(nxt)
+                tanh_follows = (isinstance(cell, LICell) and not isinstance(nxt, StateStorage)
+                                and idx + 2 < n and isinstance(branch[idx + 2], HipTanh))
+                plan.append(("norm_neuron", idx, 3 if tanh_follows else 2))
+                idx += 3 if tanh_follows else 2
+            else:
+                plan.append(("layer", idx, 1))
+                idx += 1
+        return plan
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, X: torch.Tensor, state: Optional[ListState] = None) -> Tuple[torch.Tensor, ListState]:
+        """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence)."""
+        out = []
+        out_state = []
+        state = [None] * len(self.net) if state is None else state
+        for branch, flags, plan, branch_state in zip(self.net, self.branch_state, self._plan, state):
+            branch_state = [None] * len(branch) if branch_state is None else branch_state
+            Y = X
+            for kind, idx, span in plan:
+                if kind == "norm_neuron":
+                    holder = branch[idx + 1]
+                    cell = _neuron_cell(holder)
+                    neuron = cell.kind
+                    if span == 3:
+                        neuron = _hip.NEURON_LI_TANH
+                    old = branch_state[idx + 1]
+                    Y, new = HF.affine_neuron(Y, neuron, old, bn=branch[idx], params=cell.params)
+                    if isinstance(holder, StateStorage):
+                        holder.record(old, Y, new)
+                    branch_state[idx + 1] = new
+                elif flags[idx]:
+                    Y, branch_state[idx] = branch[idx](Y, branch_state[idx])
+                else:
+                    Y = branch[idx](Y)
+            out.append(Y)
+            out_state.append(branch_state)
+        if self.merge == "residual":
+            merged = HF.sum_tensors(out)
+        elif self.merge == "dense":
+            merged = HF.concat_channels(out)
+        else:
+            merged = out[0]
+        return merged, out_state
+
+
+#####################################################################
+#                         Model Generator                           #
+#####################################################################
+class ModelGen(nn.Module):
+    """Base class of the backbone / neck / head generators (generator.py:206-276)."""
+
+    def __init__(self, cfg, in_channels: int = 2, init_weights: bool = True) -> None:
+        super().__init__()
+        self.out_channels = 0
+        self.net_cfg = self._load_cfg(cfg)
+        self._net_generator(in_channels)
+        if init_weights:
+            # generator.py:245-256: Kaiming-normal (fan_out, relu) convs, BatchNorm weight 1
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+                elif isinstance(m, nn.BatchNorm2d):
+                    nn.init.constant_(m.weight, 1)
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+
+    def _net_generator(self, in_channels: int) -> None:
+        self.net = BlockGen(in_channels, self.net_cfg)
+        self.out_channels = self.net.out_channels
+
+    def _load_cfg(self, cfg) -> ListGen:
+        raise NotImplementedError
+
+    def forward(self, X: torch.Tensor, state: Optional[ListState] = None):
+        raise NotImplementedError
+
+
+class BackboneGen(ModelGen):
+    """Returns the tensor of the last layer (generator.py:283-295)."""
+
+    def _load_cfg(self, cfg) -> ListGen:
+        return cfg()
+
+    def forward(self, X: torch.Tensor, state: Optional[ListState]) -> Tuple[torch.Tensor, ListState]:
+        return self.net(X, state)
+
+
+class NeckGen(ModelGen):
+    """Returns the tensors stashed by the ``Return`` layers (generator.py:303-351)."""
+
+    def __init__(self, cfg, in_channels: int = 2, init_weights: bool = False):
+        super().__init__(cfg, in_channels, init_weights)
+        self.out_shape = self._search_out(self.net_cfg)
+
+    def _search_out(self, cfg) -> List[int]:
+        out: List[int] = []
+        for module in cfg:
+            if isinstance(module, Return):
+                out.append(module.out_channels)
+            elif isinstance(module, list):
+                out += self._search_out(module)
+        return out
+
+    def _load_cfg(self, cfg) -> ListGen:
+        return cfg()
+
+    def forward(self, X: torch.Tensor, state: Optional[ListState]) -> Tuple[List[torch.Tensor], ListState]:
+        out = []
+        _, state = self.net(X, state)
+        for module in self.net.modules():
+            if isinstance(module, Storage):
+                out.append(module.get_storage())
+        return out, state
+
+
+#####################################################################
+#                          Head descriptor                          #
+#####################################################################
+class Head(nn.Module):
+    """One ``HeadGen`` + ``AnchorGenerator`` per feature map; merges predictions (generator.py:359-457)."""
+
+    def __init__(self, cfg, num_classes: int, in_shape: List[int], init_weights: bool = True) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+
+        max = 0.75
+        min = 0.08
+        size_per_pix = 3
+        sizes = torch.arange(min, max, (max - min) / (len(in_shape) * size_per_pix), dtype=torch.float32)
+        sizes = sizes.reshape((-1, size_per_pix))
+        ratios = torch.tensor((0.5, 1.0, 2), dtype=torch.float32)
+
+        num_anchors = size_per_pix * len(ratios)
+        num_class_out = num_anchors * (self.num_classes + 1)
+        num_box_out = num_anchors * 4
+
+        for idx, channels in enumerate(in_shape):
+            setattr(self, f"anchor_gen_{idx}", AnchorGenerator(sizes=sizes[idx], ratios=ratios))
+            setattr(self, f"model_{idx}", HeadGen(cfg, num_box_out, num_class_out, channels, init_weights))
+
+    def forward(self, X: List[torch.Tensor], state: Optional[ListState]):
+        """-> ``(anchors[A,4], cls_preds[B,A,C+1], bbox_preds[B,A,4], state)``.
+
+        Given sequences the predictions are those of the LAST timestep (all the reference keeps,
+        ``soda.py:141-144``) and ``state`` is the state after the last timestep.
+        """
+        state = [None] * len(X) if state is None else state
+        anchors, cls_preds, bbox_preds = [], [], []
+        for idx, map in enumerate(X):
+            anchors.append(getattr(self, f"anchor_gen_{idx}")(map))
+            boxes, classes, state[idx] = getattr(self, f"model_{idx}")(map, state[idx])
+            bbox_preds.append(boxes)
+            cls_preds.append(classes)
+        anchors = torch.cat(anchors)
+        cls_preds = self._concat_preds(cls_preds)
+        cls_preds = cls_preds.reshape(cls_preds.shape[0], -1, self.num_classes + 1)
+        bbox_preds = self._concat_preds(bbox_preds)
+        bbox_preds = bbox_preds.reshape(bbox_preds.shape[0], -1, 4)
+        return anchors, cls_preds, bbox_preds, state
+
+    def _flatten_pred(self, pred: torch.Tensor) -> torch.Tensor:
+        # channels-last storage makes this permute + flatten a free view
+        return torch.flatten(torch.permute(pred, (0, 2, 3, 1)), start_dim=1)
+
+    def _concat_preds(self, preds: List[torch.Tensor]) -> torch.Tensor:
+        return torch.cat([self._flatten_pred(p) for p in preds], dim=1)
+
+
+class HeadGen(ModelGen):
+    """``cfg(box_out, cls_out)`` -> three lists: preparation, box net, class net (generator.py:465-538)."""
+
+    def __init__(self, cfg, box_out: int, cls_out: int, in_channels: int = 2, init_weights=False):
+        self.box_out = box_out
+        self.cls_out = cls_out
+        super().__init__(cfg, in_channels, init_weights)
+
+    def _net_generator(self, in_channels: int) -> None:
+        self.base_net = BlockGen(in_channels, [self.net_cfg[0]])
+        self.box_net = BlockGen(self.base_net.out_channels, [self.net_cfg[1]])
+        self.cls_net = BlockGen(self.base_net.out_channels, [self.net_cfg[2]])
+
+    def _load_cfg(self, cfg) -> ListGen:
+        return cfg(self.box_out, self.cls_out)
+
+    def forward(self, X: torch.Tensor, state: Optional[ListState]):
+        state = [None] * 3 if state is None else state
+        Y, state[0] = self.base_net(X, state[0])
+        if Y.dim() == 5 and not (any(_has_state(m) for m in self.box_net.modules())
+                                 or any(_has_state(m) for m in self.cls_net.modules())):
+            # sequence input, stateless prediction nets: only the last timestep's predictions survive
+            Y = Y[-1]
+        box, state[1] = self.box_net(Y, state[1])
+        cls, state[2] = self.cls_net(Y, state[2])
+        if box.dim() == 5:
+            box, cls = box[-1], cls[-1]
+        return box, cls, state
+
+
+def _has_state(m: nn.Module) -> bool:
+    """Modules that must see every timestep: stateful ones, and BatchNorm (running-stat updates)."""
+    if isinstance(m, nn.BatchNorm2d):
+        return True
+    return not isinstance(m, BlockGen) and _is_module_stateful(m)

@@ -1,0 +1,119 @@
+"""Generate golden vectors from the REFERENCE's own torch-only files (run in the build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+Loads ``utils/box.py``, ``utils/anchors.py`` and ``utils/roi.py`` of the reference BY FILE PATH (the
+package ``__init__`` pulls in Lightning / OpenCV which are not installed), runs them on seeded inputs
+and stores inputs + outputs in ``tests/golden/detect_*.npz``.  Only data is stored - no reference
+source.  The fixtures pin ``oracle/detect.py`` and the product's ``anchors/box/roi`` modules
+(``tests/test_oracle_detect.py``).  ``/root/reference`` never travels to the GPU box; the fixtures do.
+"""
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("SNN_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference_utils():
+    pkg = types.ModuleType("utils")
+    pkg.__path__ = []  # stub package: expose only the torch-only submodules
+    sys.modules["utils"] = pkg
+    box = _load("utils.box", os.path.join(REF, "utils", "box.py"))
+    pkg.box = box
+    anchors = _load("utils.anchors", os.path.join(REF, "utils", "anchors.py"))
+    roi = _load("utils.roi", os.path.join(REF, "utils", "roi.py"))
+    return box, anchors, roi
+
+
+def head_sizes(num_maps=3, per_pixel=3):
+    # models/generator.py:389-401 (the file itself needs python >= 3.12, so the table is rebuilt here)
+    lo, hi = 0.08, 0.75
+    sizes = torch.arange(lo, hi, (hi - lo) / (num_maps * per_pixel), dtype=torch.float32).reshape((-1, per_pixel))
+    return sizes, torch.tensor((0.5, 1.0, 2), dtype=torch.float32)
+
+
+def random_labels(gen, batch, n_boxes, n_classes, pad_rows=0):
+    out = torch.full((batch, n_boxes + pad_rows, 5), -1.0)
+    for b in range(batch):
+        for k in range(n_boxes):
+            while True:
+                xy = torch.rand(2, 2, generator=gen)
+                lo, hi = xy.min(0).values, xy.max(0).values
+                if (hi - lo).prod() > 0.01:
+                    break
+            out[b, k, 0] = float(torch.randint(0, n_classes, (1,), generator=gen))
+            out[b, k, 1:3], out[b, k, 3:5] = lo, hi
+    return out
+
+
+def main():
+    box, anchors_mod, roi_mod = load_reference_utils()
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(1234)
+    sizes, ratios = head_sizes()
+
+    # ---- anchors for the three GEN1 taps and a tiny pyramid
+    fix = {}
+    for tag, shapes in (("gen1", [(30, 38), (15, 19), (8, 10)]), ("tiny", [(4, 6), (2, 3), (1, 2)])):
+        per_map = []
+        for idx, (h, w) in enumerate(shapes):
+            g = anchors_mod.AnchorGenerator(sizes=sizes[idx].clone(), ratios=ratios.clone())
+            per_map.append(g(torch.zeros(1, 1, h, w)).clone())
+        fix[f"anchors_{tag}"] = torch.cat(per_map).numpy()
+        fix[f"shapes_{tag}"] = np.array(shapes)
+    np.savez_compressed(os.path.join(OUT, "detect_anchors.npz"), sizes=sizes.numpy(), ratios=ratios.numpy(), **fix)
+
+    # ---- box primitives
+    a = torch.rand(64, 2, 2, generator=gen)
+    boxes_a = torch.cat([a.min(1).values, a.max(1).values + 0.01], dim=1)
+    b = torch.rand(7, 2, 2, generator=gen)
+    boxes_b = torch.cat([b.min(1).values, b.max(1).values + 0.01], dim=1)
+    offs = torch.randn(64, 4, generator=gen)
+    np.savez_compressed(
+        os.path.join(OUT, "detect_box.npz"),
+        boxes_a=boxes_a.numpy(), boxes_b=boxes_b.numpy(), offs=offs.numpy(),
+        iou=box.box_iou(boxes_a, boxes_b).numpy(),
+        c2c=box.box_corner_to_center(boxes_a).numpy(),
+        c2c_inv=box.box_center_to_corner(box.box_corner_to_center(boxes_a)).numpy(),
+        offset_boxes=box.offset_boxes(boxes_a, boxes_a.flip(0)).numpy(),
+        offset_inverse=box.offset_inverse(boxes_a, offs).numpy(),
+    )
+
+    # ---- RoI targets on the GEN1 anchor set: plain labels and labels with padding rows (-1)
+    anc = torch.from_numpy(fix["anchors_gen1"])
+    cases = {}
+    for tag, pad in (("plain", 0), ("padded", 2)):
+        labels = random_labels(gen, batch=3, n_boxes=2, n_classes=2, pad_rows=pad)
+        off, mask, cls = roi_mod.RoI(0.4)(anc, labels.clone())
+        cases.update({f"labels_{tag}": labels.numpy(), f"offset_{tag}": off.numpy(),
+                      f"mask_{tag}": mask.numpy(), f"cls_{tag}": cls.numpy()})
+    np.savez_compressed(os.path.join(OUT, "detect_roi.npz"), iou_threshold=0.4, **cases)
+
+    # ---- multibox_detection (NMS decode) on the tiny pyramid
+    anc_t = torch.from_numpy(fix["anchors_tiny"])
+    A = anc_t.shape[0]
+    probs = torch.softmax(3 * torch.randn(2, A, 3, generator=gen), dim=2)
+    offp = 0.5 * torch.randn(2, A, 4, generator=gen)
+    det = box.multibox_detection(probs.clone(), offp.clone(), anc_t)
+    np.savez_compressed(os.path.join(OUT, "detect_nms.npz"), probs=probs.numpy(), offsets=offp.numpy(),
+                        detections=det.numpy())
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
