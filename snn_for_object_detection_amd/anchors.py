@@ -25,16 +25,18 @@ class AnchorGenerator(nn.Module):
 
     def _cal_anchors(self, X: torch.Tensor) -> None:
         rows, cols = X.shape[-2:]
-        dev = X.device
-        per_pixel = len(self.sizes) * len(self.ratios)
+        # one-off host-side set-up: evaluated on the CPU (bit-identical on every device), then moved
+        dev = torch.device("cpu")
+        sizes, ratios = self.sizes.detach().cpu(), self.ratios.detach().cpu()
+        per_pixel = len(sizes) * len(ratios)
         # pixel centres in normalised image coordinates
         cy = (torch.arange(rows, device=dev) + 0.5) * (1.0 / rows)
         cx = (torch.arange(cols, device=dev) + 0.5) * (1.0 / cols)
         gy, gx = torch.meshgrid(cy, cx, indexing="ij")
         gy, gx = gy.reshape(-1), gx.reshape(-1)
         # box extents for every (ratio, size) pair, corrected for the map's aspect
-        bw = torch.cat([self.sizes * r for r in self.ratios]) * rows / cols
-        bh = torch.cat([self.sizes / r for r in self.ratios]) * cols / rows
+        bw = torch.cat([sizes * r for r in ratios]) * rows / cols
+        bh = torch.cat([sizes / r for r in ratios]) * cols / rows
         corners = torch.stack((-bw, -bh, bw, bh)).T.repeat(rows * cols, 1) / 2
         centres = torch.stack([gx, gy, gx, gy], dim=1).repeat_interleave(per_pixel, dim=0)
-        self.anchors = centres + corners
+        self.anchors = (centres + corners).to(X.device)

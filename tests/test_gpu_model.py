@@ -1,0 +1,142 @@
+"""End-to-end parity of the generated SODa / TinyYolo step on a real MI355X against the CPU oracle
+(time-outer restatement of the reference), same description, same weights, same seeded inputs.
+
+Stated tolerance (fp32 parity mode): loss and predictions within 1e-4 relative, gradients within 1e-3
+(L2, relative), spike tensors equal except neurons whose pre-reset potential sits within 1e-5 of the
+threshold (SURVEY section 7 "spike-flip sensitivity").
+"""
+import pytest
+import torch
+
+from tests.util import make_pair, rel_err, synthetic_events, synthetic_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import snn_for_object_detection_amd as pkg
+    return pkg
+
+
+def test_tiny_yolo_train_step_matches_oracle(S):
+    T, B, H, W = 4, 2, 32, 48
+    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
+    X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B)
+    product.train()
+    oracle.train()
+    loss_ref = oracle.training_step((X, labels))
+    loss_ref.backward()
+    loss = product.training_step((X.cuda(), labels.cuda()))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    ref_grads = dict(oracle.named_parameters())
+    worst = 0.0
+    for name, p in product.named_parameters():
+        if not p.requires_grad:
+            continue
+        g_ref = ref_grads[name].grad
+        assert p.grad is not None and g_ref is not None, name
+        if g_ref.norm() > 1e-8:
+            worst = max(worst, rel_err(p.grad, g_ref))
+    assert worst < 1e-3, worst
+    # running statistics took T sequential updates
+    bn_p = product.base_net.net.net[0][1]
+    bn_r = oracle.base_net.net.net[0][1]
+    assert rel_err(bn_p.running_mean, bn_r.running_mean) < 1e-5
+    assert rel_err(bn_p.running_var, bn_r.running_var) < 1e-5
+    assert int(bn_p.num_batches_tracked) == T
+
+
+def test_tiny_yolo_eval_spikes_and_preds_match_oracle(S):
+    T, B, H, W = 5, 2, 32, 48
+    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0, state_storage=True)
+    X = synthetic_events(T, B, H, W, p=0.1, seed=3)
+    # warm the running statistics with one train pass on both sides, then evaluate
+    product.train()
+    oracle.train()
+    with torch.no_grad():
+        product(X.cuda())
+        oracle(X)
+    product.eval()
+    oracle.eval()
+    with torch.no_grad():
+        anchors, cls, bbox = product(X.cuda())
+        anchors_r, cls_r, bbox_r = oracle(X)
+    assert torch.equal(anchors.cpu(), anchors_r)
+    assert rel_err(cls, cls_r) < 1e-4 and rel_err(bbox, bbox_r) < 1e-4
+    taps, taps_r = product.spike_taps(), oracle.spike_taps()
+    assert set(taps) == set(taps_r) and len(taps) == 22
+    total = mism = 0
+    for name, z in taps.items():
+        zr = taps_r[name]
+        assert z.shape == zr.shape, name
+        if "head_net" in name:  # LI taps are real-valued
+            assert rel_err(z, zr) < 1e-4, name
+        else:
+            total += zr.numel()
+            mism += int((z.cpu() != zr).sum())
+    assert mism <= 1e-5 * total, (mism, total)
+
+
+def test_layer_major_equals_time_outer_on_device(S):
+    T, B, H, W = 4, 1, 32, 48
+    torch.manual_seed(0)
+    model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    X = synthetic_events(T, B, H, W, p=0.1, seed=5).cuda()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    _, cls_a, box_a = model(X)
+    loss_a = (cls_a.square().mean() + box_a.square().mean())
+    grads_a = torch.autograd.grad(loss_a, [p for p in model.parameters() if p.requires_grad])
+    model.load_state_dict(sd)
+    _, cls_b, box_b = model(X, time_outer=True)
+    loss_b = (cls_b.square().mean() + box_b.square().mean())
+    grads_b = torch.autograd.grad(loss_b, [p for p in model.parameters() if p.requires_grad])
+    assert torch.equal(cls_a, cls_b) and torch.equal(box_a, box_b)
+    for ga, gb in zip(grads_a, grads_b):
+        assert rel_err(ga, gb) < 1e-5
+
+
+def test_predict_streaming_matches_oracle(S):
+    H, W = 32, 48
+    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
+    product.eval()
+    oracle.eval()
+    X = synthetic_events(6, 1, H, W, p=0.1, seed=7)[:, 0]
+    st_p = st_r = None
+    with torch.no_grad():
+        for t in range(X.shape[0]):
+            det_p, st_p = product.predict(X[t].cuda(), st_p)
+            det_r, st_r = oracle.predict(X[t], st_r)
+    assert det_p.shape == det_r.shape
+    if det_r.numel():
+        assert torch.equal(det_p[:, 0].cpu(), det_r[:, 0])
+        assert rel_err(det_p[:, 1:], det_r[:, 1:]) < 1e-4
+
+
+def test_readme_style_generated_net(S):
+    """A user description (Pool('S'), residual 1x1 branch, k=5/7 convs) runs and matches the oracle."""
+    from oracle.net import BlockRef
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm, Pool, Residual
+
+    def cfg():
+        def conv(c, k=3, s=1):
+            return (Conv(c, stride=s, kernel_size=k), Norm(), LIF())
+        return [*conv(8, 7, 2), Residual([[*conv(8, 5)], [Conv(8, 1)]]), Pool("S"), *conv(16), Pool("M")]
+
+    torch.manual_seed(4)
+    blk = BlockGen(2, cfg())
+    ref = BlockRef(2, cfg())
+    ref.load_state_dict(blk.state_dict())
+    blk = blk.cuda()
+    X = synthetic_events(3, 2, 40, 36, p=0.3, seed=2)
+    out, _ = blk(X.cuda())
+    state, outs = None, []
+    for t in range(3):
+        o, state = ref(X[t], state)
+        outs.append(o)
+    out_r = torch.stack(outs)
+    assert out.shape == out_r.shape
+    assert (out.cpu() != out_r).float().mean().item() < 1e-3

@@ -1,0 +1,287 @@
+"""Operator-level parity on a real MI355X: every HIP entry point, called through the C ABI (ctypes),
+against torch's CPU kernels / the oracle on identical seeded inputs.
+
+Tolerances: conv = fp32 MFMA fmaf chain vs oneDNN's accumulation order -> rel 1e-5 (L2);
+pointwise / scans on identical inputs -> 1e-6; spikes -> exact except neurons within 1e-5 of threshold.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import neurons as ON
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def HF(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from snn_for_object_detection_amd import functional
+    return functional
+
+
+CONV_CASES = [
+    # T, B, Cin, H, W, Cout, k, s
+    (2, 2, 2, 17, 23, 64, 3, 2),      # first layer: Cin=2 scalar gather, K=18
+    (2, 1, 32, 12, 19, 32, 3, 1),     # BN=32 tile
+    (1, 2, 64, 9, 11, 128, 3, 2),     # stride 2, odd sizes, BN=128 tile
+    (2, 1, 128, 8, 10, 64, 1, 1),     # 1x1
+    (1, 1, 96, 7, 5, 36, 1, 1),       # head box conv: Cout=36
+    (1, 2, 256, 4, 5, 27, 1, 1),      # head cls conv: Cout=27 (not a multiple of 4)
+    (1, 1, 8, 13, 9, 12, 5, 1),       # k=5 (README example nets)
+    (1, 1, 4, 16, 15, 8, 7, 2),       # k=7 stride 2
+    (3, 2, 64, 30, 38, 64, 3, 1),     # several 128-pixel tiles, K loop of 18 stages
+]
+
+
+@pytest.mark.parametrize("T,B,Cin,H,W,Cout,k,s", CONV_CASES)
+def test_conv2d_fwd_bwd(HF, T, B, Cin, H, W, Cout, k, s):
+    torch.manual_seed(T * 1000 + Cin + Cout + k)
+    x = torch.randn(T, B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    pad = int(k / 2)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr.flatten(0, 1), wr, stride=s, padding=pad)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+
+    xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+    yd = HF.conv2d(xd, wd, stride=s, padding=pad)
+    assert yd.shape == (T, B) + yr.shape[1:]
+    yd.backward(gy.view(yd.shape).cuda())
+    assert rel_err(yd.flatten(0, 1), yr) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    assert rel_err(wd.grad, wr.grad) < 1e-5
+
+
+def test_conv2d_single_step_and_determinism(HF):
+    torch.manual_seed(3)
+    x = torch.randn(2, 16, 10, 12).cuda().requires_grad_()
+    w = (torch.randn(24, 16, 3, 3) / 12).cuda().requires_grad_()
+    y1 = HF.conv2d(x, w, 1, 1)
+    assert y1.shape == (2, 24, 10, 12)
+    g = torch.randn_like(y1)
+    (gx1, gw1) = torch.autograd.grad(y1, (x, w), g)
+    y2 = HF.conv2d(x, w, 1, 1)
+    (gx2, gw2) = torch.autograd.grad(y2, (x, w), g)
+    assert torch.equal(y1, y2) and torch.equal(gx1, gx2) and torch.equal(gw1, gw2)  # bitwise reproducible
+    ref = F.conv2d(x.detach().cpu(), w.detach().cpu(), padding=1)
+    assert rel_err(y1, ref) < 1e-5
+
+
+def _oracle_norm_neuron(y, bn, cell, tanh=False, state=None):
+    outs = []
+    for t in range(y.shape[0]):
+        x = bn(y[t]) if bn is not None else y[t]
+        if cell is not None:
+            o, state = cell(x, state)
+        else:
+            o = x
+        outs.append(torch.tanh(o) if tanh else o)
+    return torch.stack(outs), state
+
+
+@pytest.mark.parametrize("C,H,W,T,B", [(32, 6, 7, 5, 3), (64, 12, 19, 8, 2), (6, 5, 4, 3, 2)])
+def test_bn_lif_fused_train(HF, C, H, W, T, B):
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(C + T)
+    y = 2.5 * torch.randn(T, B, C, H, W) + 0.3
+    gamma = 1.0 + 0.2 * torch.randn(C)
+
+    bn = torch.nn.BatchNorm2d(C)
+    bn.bias = None
+    bn.weight.data.copy_(gamma)
+    yr = y.clone().requires_grad_()
+    cell = ON.LIFCell()
+    # run the oracle step by step, keeping v_dec for the near-threshold analysis
+    state, zs, vdecs = None, [], []
+    for t in range(T):
+        xt = bn(yr[t])
+        if state is None:
+            state = cell.initial_state(xt)
+        i_new = state.i + xt
+        vdecs.append((state.v + 0.1 * ((0.0 - state.v) + i_new)).detach())
+        z, state = cell(xt, state)
+        zs.append(z)
+    zr = torch.stack(zs)
+    gz = torch.randn_like(zr)
+    (zr * gz).sum().backward()
+
+    bnd = HipBatchNorm2d(C)
+    bnd.bias = None
+    bnd.weight.data.copy_(gamma)
+    bnd = bnd.cuda()
+    yd = y.cuda().requires_grad_()
+    zd, st = HF.affine_neuron(yd, _hip.NEURON_LIF, None, bn=bnd)
+    (zd * gz.cuda()).sum().backward()
+
+    zd_c = zd.detach().cpu()
+    mism = zd_c != zr.detach()
+    assert mism.float().mean().item() < 1e-4
+    if mism.any():  # the first disagreement of a neuron must sit on the threshold
+        first = mism.float().cumsum(0).eq(1) & mism
+        assert (torch.stack(vdecs)[first] - 1.0).abs().max().item() < 1e-5
+    if not mism.any():
+        assert rel_err(st.v, state.v) < 1e-6 and rel_err(st.i, state.i) < 1e-6
+        assert rel_err(yd.grad, yr.grad) < 2e-5
+        assert rel_err(bnd.weight.grad, bn.weight.grad) < 2e-5
+    assert rel_err(bnd.running_mean, bn.running_mean) < 1e-6
+    assert rel_err(bnd.running_var, bn.running_var) < 1e-6
+    assert int(bnd.num_batches_tracked) == int(bn.num_batches_tracked) == T
+
+
+def test_bn_li_tanh_fused_and_eval_mode(HF):
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(11)
+    T, B, C, H, W = 6, 2, 16, 5, 6
+    y = torch.randn(T, B, C, H, W) * 3
+    for training in (True, False):
+        bn = torch.nn.BatchNorm2d(C)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.uniform_(-0.2, 0.2)
+        bn.running_mean.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bnd = HipBatchNorm2d(C)
+        bnd.load_state_dict(bn.state_dict())
+        bn.train(training)
+        bnd.train(training)
+        bnd = bnd.cuda()
+        yr = y.clone().requires_grad_()
+        outr, str_ = _oracle_norm_neuron(yr, bn, ON.LICell(), tanh=True)
+        g = torch.randn_like(outr)
+        (outr * g).sum().backward()
+        yd = y.cuda().requires_grad_()
+        outd, std = HF.affine_neuron(yd, _hip.NEURON_LI_TANH, None, bn=bnd)
+        (outd * g.cuda()).sum().backward()
+        assert rel_err(outd, outr) < 1e-6
+        assert rel_err(std.v, str_.v) < 1e-6 and rel_err(std.i, str_.i) < 1e-6
+        assert rel_err(yd.grad, yr.grad) < 2e-5
+        assert rel_err(bnd.weight.grad, bn.weight.grad) < 2e-5
+        assert rel_err(bnd.bias.grad, bn.bias.grad) < 2e-5
+
+
+def test_lif_state_carry_equals_sequence(HF):
+    """T single-step calls with carried state (reference protocol) == one sequence call, bitwise; and
+    gradients flow through the carried state (time-outer BPTT)."""
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(5)
+    T, B, C, H, W = 7, 2, 8, 4, 5
+    x = (1.2 * torch.rand(T, B, C, H, W)).cuda()
+    xs = x.clone().requires_grad_()
+    z_seq, st_seq = HF.affine_neuron(xs, _hip.NEURON_LIF, None)
+    g = torch.randn_like(z_seq)
+    (z_seq * g).sum().backward()
+    xt = x.clone().requires_grad_()
+    state, zs = None, []
+    for t in range(T):
+        z, state = HF.affine_neuron(xt[t], _hip.NEURON_LIF, state)
+        zs.append(z)
+    z_loop = torch.stack(zs)
+    (z_loop * g).sum().backward()
+    assert torch.equal(z_seq, z_loop)
+    assert torch.equal(st_seq.v, state.v) and torch.equal(st_seq.i, state.i)
+    assert rel_err(xt.grad, xs.grad) < 1e-6
+    # and against the oracle
+    cell, st, zr = ON.LIFCell(), None, []
+    xc = x.cpu().requires_grad_()
+    for t in range(T):
+        z, st = cell(xc[t], st)
+        zr.append(z)
+    zr = torch.stack(zr)
+    (zr * g.cpu()).sum().backward()
+    assert torch.equal(z_seq.cpu(), zr)
+    assert rel_err(xs.grad, xc.grad) < 1e-6
+
+
+def test_standalone_norm_matches_batchnorm(HF):
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(2)
+    x = torch.randn(4, 10, 9, 7) * 2 + 1
+    bn = torch.nn.BatchNorm2d(10)
+    bnd = HipBatchNorm2d(10).cuda()
+    xr, xd = x.clone().requires_grad_(), x.cuda().requires_grad_()
+    yr, yd = bn(xr), bnd(xd)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    yd.backward(g.cuda())
+    assert rel_err(yd, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 2e-5
+    assert rel_err(bnd.weight.grad, bn.weight.grad) < 2e-5 and rel_err(bnd.bias.grad, bn.bias.grad) < 2e-5
+
+
+def test_merges_pool_upsample_activation(HF):
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(9)
+    a, b, c = torch.randn(2, 3, 8, 6, 5), torch.randn(2, 3, 12, 6, 5), torch.randn(2, 3, 8, 6, 5)
+    ad, bd, cd = (t.cuda().requires_grad_() for t in (a, b, c))
+    ar, br, cr = (t.clone().requires_grad_() for t in (a, b, c))
+    outd = HF.concat_channels([HF.sum_tensors([ad, cd]), bd])
+    outr = torch.cat([torch.stack([ar, cr]).sum(0), br], dim=2)
+    g = torch.randn_like(outr)
+    outd.backward(g.cuda())
+    outr.backward(g)
+    assert torch.equal(outd.cpu(), outr)
+    for d, r in ((ad, ar), (bd, br), (cd, cr)):
+        assert torch.equal(d.grad.cpu(), r.grad)
+
+    x = torch.randn(3, 6, 9, 11)
+    pools = ((_hip.POOL_AVG, 2, 2, lambda t: F.avg_pool2d(t, 2, 2)), (_hip.POOL_MAX, 2, 2, lambda t: F.max_pool2d(t, 2, 2)),
+             (_hip.POOL_SUM, 2, 2, lambda t: F.avg_pool2d(t, 2, 2) * 2 * 2), (_hip.POOL_AVG, 3, 2, lambda t: F.avg_pool2d(t, 3, 2)),
+             (_hip.POOL_MAX, 3, 1, lambda t: F.max_pool2d(t, 3, 1)))
+    for kind, k, s, ref in pools:
+        xr, xd = x.clone().requires_grad_(), x.cuda().requires_grad_()
+        yr = ref(xr)
+        yd = HF.pool2d(xd, kind, k, s)
+        gg = torch.randn_like(yr)
+        yr.backward(gg)
+        yd.backward(gg.cuda())
+        assert rel_err(yd, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+
+    xr, xd = x.clone().requires_grad_(), x.cuda().requires_grad_()
+    yr, yd = F.interpolate(xr, scale_factor=2, mode="nearest"), HF.upsample_nearest(xd, 2)
+    gg = torch.randn_like(yr)
+    yr.backward(gg)
+    yd.backward(gg.cuda())
+    assert torch.equal(yd.cpu(), yr) and rel_err(xd.grad, xr.grad) < 1e-6
+
+    for act, ref in ((_hip.ACT_RELU, torch.relu), (_hip.ACT_SILU, F.silu), (_hip.ACT_TANH, torch.tanh)):
+        xr, xd = x.clone().requires_grad_(), x.cuda().requires_grad_()
+        yr, yd = ref(xr), HF.activation(xd, act)
+        ga = torch.randn_like(yr)
+        yr.backward(ga)
+        yd.backward(ga.cuda())
+        assert rel_err(yd, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-5
+
+
+def test_layout_roundtrip_and_events(HF):
+    torch.manual_seed(1)
+    for C in (1, 2, 3, 7, 64):
+        x = torch.randn(3, C, 9, 14).cuda()
+        cl = HF._raw_to_cl(x)
+        assert HF.is_channels_last(cl) and torch.equal(cl, x)
+        assert torch.equal(HF._raw_to_nchw(cl).contiguous(), x)
+    T, H, W, n = 4, 12, 16, 500
+    g = torch.Generator().manual_seed(0)
+    tb = torch.randint(0, T, (n,), generator=g, dtype=torch.int32)
+    xs = torch.randint(0, W + 3, (n,), generator=g, dtype=torch.int32)  # some beyond the frame: clipped
+    ys = torch.randint(0, H, (n,), generator=g, dtype=torch.int32)
+    ps = torch.randint(0, 2, (n,), generator=g, dtype=torch.int32)
+    want = torch.zeros(T, 2, H, W)
+    want[tb.long(), ps.long(), ys.long(), xs.clamp(0, W - 1).long()] = 1
+    got = HF.events_to_frames(tb.cuda(), xs.cuda(), ys.cuda(), ps.cuda(), T, H, W)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_errors_surface_as_exceptions(HF):
+    from snn_for_object_detection_amd import Pool, Residual, BlockGen, Conv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HF.conv2d(torch.zeros(1, 2, 4, 4), torch.zeros(3, 2, 3, 3), 1, 1)
+    with pytest.raises(ValueError):
+        Pool("X")
+    with pytest.raises(RuntimeError, match="residual"):
+        BlockGen(4, Residual([[Conv(8, 1)], [Conv(6, 1)]]))
+    with pytest.raises(RuntimeError, match="channels"):
+        HF.conv2d(torch.zeros(1, 2, 4, 4).cuda(), torch.zeros(3, 5, 3, 3).cuda(), 1, 1)

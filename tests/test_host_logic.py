@@ -1,0 +1,79 @@
+"""CPU-side checks: description API, module-tree / state_dict layout, C-ABI symbol export, build."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import snn_for_object_detection_amd as S
+from oracle.net import SODaRef
+
+
+def test_tiny_yolo_structure_and_param_count():
+    m = S.TinyYolo(num_classes=2, time_window=0)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 4_228_544
+    kinds = [type(x).__name__ for x in m.modules()]
+    assert kinds.count("HipConv2d") == 48 and kinds.count("HipBatchNorm2d") == 22
+    assert kinds.count("LIFCell") == 19 and kinds.count("LICell") == 3 and kinds.count("Storage") == 3
+    assert m.neck_net.out_shape == [256, 256, 256]
+    m7 = S.TinyYolo(num_classes=7, time_window=0)
+    assert sum(p.numel() for p in m7.parameters() if p.requires_grad) == 4_263_104
+
+
+def test_state_dict_layout_is_the_reference_layout():
+    m = S.TinyYolo(num_classes=2)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "base_net.net.net.0.0.weight"                    # ModuleList nesting, generator.py:115,143
+    assert "base_net.net.net.0.1.running_mean" in keys and "base_net.net.net.0.1.bias" not in keys
+    assert "head_net.model_0.base_net.net.0.0.net.0.0.weight" in keys  # generator.py:403-413,522-525
+    assert "head_net.anchor_gen_2.sizes" in keys
+    ref = SODaRef(m, 2)
+    assert list(ref.state_dict().keys()) == keys                       # oracle and product interchange weights
+    ref.load_state_dict(m.state_dict())
+    w = m.base_net.net.net[0][0].weight
+    assert w.shape == (64, 2, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()   # OHWI storage for the kernels
+
+
+def test_block_state_tree_and_fusion_plan():
+    blk = S.BlockGen(4, [S.Conv(8), S.Norm(), S.LIF(), S.Dense([[S.Conv(8, 1), S.Norm(), S.LI(), S.Tanh()], [S.Pass()]])])
+    assert blk.out_channels == 16
+    assert blk.branch_state == [[False, False, True, True]]
+    assert blk._plan[0] == [("layer", 0, 1), ("norm_neuron", 1, 2), ("layer", 3, 1)]
+    inner = blk.net[0][3]
+    assert inner.merge == "dense" and inner._plan[0] == [("layer", 0, 1), ("norm_neuron", 1, 3)]
+    with pytest.raises(RuntimeError):
+        S.BlockGen(4, S.Residual([[S.Conv(8, 1)], [S.Conv(6, 1)]]))
+    with pytest.raises(ValueError):
+        S.Pool("Q")
+    with pytest.raises(NotImplementedError):
+        S.SODa(num_classes=2)
+
+
+def test_product_refuses_cpu_tensors():
+    m = S.TinyYolo(num_classes=2, time_window=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 1, 2, 32, 48))
+
+
+def test_c_abi_exports_every_declared_symbol(hip_lib):
+    from snn_for_object_detection_amd import _hip
+    header = open(os.path.join(os.path.dirname(_hip._HERE), "include", "snn_hip.h")).read()
+    declared = set(re.findall(r"\b(snn_[a-z0-9_]+)\s*\(", header))
+    declared.discard("snn_neuron_params")
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    raw = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert hip_lib.snn_abi_version() == _hip.ABI_VERSION
+    # shape planning helpers are host-only and callable without a GPU
+    assert hip_lib.snn_conv2d_wgrad_splitk(160, 120, 152, 32, 32, 3, 3) >= 1
+    assert hip_lib.snn_bn_stats_partial_size(32, 5 * 120 * 152, 64) > 0
+    assert hip_lib.snn_affine_neuron_bwd_sums_size(32, 5 * 120 * 152, 64) > 0
+
+
+def test_neuron_constants_match_oracle():
+    from oracle.neurons import neuron_constants
+    p = S.functional.neuron_params()
+    assert (p.c_mem, p.c_syn, p.v_leak, p.v_th, p.v_reset, p.alpha) == tuple(
+        torch.tensor(neuron_constants(), dtype=torch.float32).tolist())
