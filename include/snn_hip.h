@@ -174,9 +174,11 @@ int snn_upsample_bwd(const float* gy, float* gx, int64_t N, int H, int W, int C,
 
 /* ---------------------------------------------------------------- optimizer
  * torch.optim.Adamax(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) single-tensor step
- * (soda.py:135-136) over a flat parameter / gradient buffer. */
+ * (soda.py:135-136) over a flat parameter / gradient buffer; grad is multiplied by grad_scale first
+ * (1/world_size after the data-parallel SUM all-reduce, DDP's gradient averaging). */
 int snn_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_inf,
-                    int64_t n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+                    int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                    float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- event voxelisation
  * utils/datasets.py:378-435: scatter events (t_bin, p, y, x) into binary frames [T][H][W][2]

@@ -55,7 +55,7 @@ SIGNATURES = {
     "snn_pool_bwd": (c_int, [_I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "snn_upsample_fwd": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "snn_upsample_bwd": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),
-    "snn_adamax_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
+    "snn_adamax_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
     "snn_events_to_frames": (c_int, [_P, _P, _P, _P, _L, _P, _I, _I, _I, _P]),
 }
 
@@ -81,10 +81,18 @@ def load():
     return lib
 
 
+PROFILER = None  # optional object with .before(name, args) -> token and .after(token); see profiler.py
+
+
 def call(name: str, *args) -> None:
     """Invoke an int-returning entry point; non-zero -> RuntimeError with the library's message."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if PROFILER is not None:
+        token = PROFILER.before(name, args)
+        rc = getattr(lib, name)(*args)
+        PROFILER.after(token)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.snn_last_error()
         raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -238,11 +238,11 @@ __global__ void k_upsample_bwd(const float* __restrict__ gy, float* __restrict__
 
 // ------------------------------------------------------------------------------------------ optimizer
 __global__ void k_adamax(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                         float* __restrict__ u, int64_t n, float lr, float b1, float b2, float eps, float clr) {
+                         float* __restrict__ u, int64_t n, float w1, float b2, float eps, float clr, float gscale) {
     for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads) {
-        float ge = g[e];
+        float ge = g[e] * gscale;  // gscale = 1/world_size after a SUM all-reduce (exact for powers of two)
         // torch.optim.Adamax single-tensor: exp_avg.lerp_(grad, 1-beta1); exp_inf = max(exp_inf*beta2, |g|+eps)
-        float me = m[e] + (ge - m[e]) * (1.0f - b1);
+        float me = m[e] + w1 * (ge - m[e]);
         float ue = fmaxf(u[e] * b2, fabsf(ge) + eps);
         m[e] = me;
         u[e] = ue;
@@ -387,13 +387,14 @@ extern "C" int snn_upsample_bwd(const float* gy, float* gx, int64_t N, int H, in
 }
 
 extern "C" int snn_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_inf, int64_t n, float lr,
-                               float beta1, float beta2, float eps, int step, void* stream) {
+                               float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
     SNN_REQUIRE(param && grad && exp_avg && exp_inf && n > 0 && step >= 1, "snn_adamax_step: bad arguments");
     // clr = lr / (1 - beta1^step)
     double bias_corr = 1.0 - pow((double)beta1, (double)step);
     float clr = (float)((double)lr / bias_corr);
+    float w1 = (float)(1.0 - (double)beta1);
     hipLaunchKernelGGL(k_adamax, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_inf, n, lr, beta1, beta2, eps, clr);
+                       exp_inf, n, w1, beta2, eps, clr, grad_scale);
     SNN_CHECK_LAUNCH("snn_adamax_step");
     return 0;
 }

@@ -122,12 +122,39 @@ def _dims5(x: torch.Tensor):
     return T, B, C, H, W
 
 
+# ------------------------------------------------------------------------------------------- gradient slots
+class GradSlot:
+    """Destination of a parameter's gradient inside a flat gradient buffer (``trainer.FlatTrainer``).
+
+    When a parameter carries ``_snn_grad_slot`` the backward kernels write (first use in a step) or
+    accumulate (later uses) its gradient straight into ``buf`` - the buffer the data-parallel all-reduce
+    and the fused Adamax step work on - and autograd receives no gradient for it (zero copies).
+    ``buf`` is dense in the parameter's STORAGE order (OHWI for conv weights).
+    """
+
+    __slots__ = ("buf", "written")
+
+    def __init__(self, buf: torch.Tensor):
+        self.buf = buf
+        self.written = False
+
+    def claim(self) -> int:
+        """-> the ``accumulate`` flag for the kernel and mark the slot as holding data."""
+        acc = 1 if self.written else 0
+        self.written = True
+        return acc
+
+
+def _slot_of(param) -> Optional[GradSlot]:
+    return getattr(param, "_snn_grad_slot", None) if param is not None else None
+
+
 # ------------------------------------------------------------------------------------------- conv
 class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None):
         _require_device(x, "conv2d input")
         _require_device(weight, "conv2d weight")
         T, B, Cin, H, W = _dims5(x)
@@ -144,6 +171,7 @@ class _Conv2d(Function):
                   Ho, Wo, Cout, KH, KW, stride, pad, 0, _stream())
         ctx.save_for_backward(x, w_ohwi)
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
+        ctx.slot = slot
         return y
 
     @staticmethod
@@ -162,16 +190,20 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
             ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
-            dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
-            _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, dw_ohwi.data_ptr(), T * B, H, W,
-                      Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
-            dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None
+            if ctx.slot is not None:
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, ctx.slot.buf.data_ptr(), T * B,
+                          H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, st)
+            else:
+                dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, dw_ohwi.data_ptr(), T * B, H,
+                          W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
+                dw = dw_ohwi.permute(0, 3, 1, 2)
+        return dx, dw, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
     seq, single = as_sequence(x)
-    y = _Conv2d.apply(seq, weight, int(stride), int(padding))
+    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight))
     return y[0] if single else y
 
 
@@ -194,7 +226,7 @@ class _AffineNeuron(Function):
 
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, cfg):
-        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params) = cfg
+        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot) = cfg
         _require_device(y, "norm/neuron input")
         y = _raw_to_cl(y)
         T, B, C, H, W = _dims5(y)
@@ -239,6 +271,7 @@ class _AffineNeuron(Function):
                   out.data_ptr(), C, _ptr(vT) if has_state else None, _ptr(iT) if has_state else None, _ptr(vdec),
                   T, M, C, params, st)
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
+        ctx.slots = (g_slot, b_slot)
         ctx.has_v0 = v0 is not None
         ctx.has_i0 = i0 is not None
         state = vdec if neuron == _hip.NEURON_LIF else (out if neuron == _hip.NEURON_LI_TANH else None)
@@ -284,11 +317,24 @@ class _AffineNeuron(Function):
         dy = dgamma = dbias = None
         if need_sums:
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)
-            dgamma = torch.empty((C,), device=dev, dtype=_F32) if need_gamma else None
-            dbias = torch.empty((C,), device=dev, dtype=_F32) if need_bias else None
-            _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
-                      invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), _ptr(dgamma),
-                      _ptr(dbias), 0, st)
+            g_slot, b_slot = ctx.slots
+            slotted = (g_slot is not None or not need_gamma) and (b_slot is not None or not need_bias)
+            if slotted and (need_gamma or need_bias):
+                # gradients go straight into the flat gradient buffer; both share one accumulate flag
+                acc = (g_slot or b_slot).written
+                for s_ in (g_slot, b_slot):
+                    if s_ is not None:
+                        s_.claim()
+                _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
+                          invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                          g_slot.buf.data_ptr() if (g_slot is not None and need_gamma) else None,
+                          b_slot.buf.data_ptr() if (b_slot is not None and need_bias) else None, 1 if acc else 0, st)
+            else:
+                dgamma = torch.empty((C,), device=dev, dtype=_F32) if need_gamma else None
+                dbias = torch.empty((C,), device=dev, dtype=_F32) if need_bias else None
+                _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
+                          invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                          _ptr(dgamma), _ptr(dbias), 0, st)
             if need_y and not use_running:
                 # in place: dy overwrites gx
                 _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), C, coef[0].data_ptr(), coef[1].data_ptr(),
@@ -331,7 +377,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     v0 = i0 = None
     if state is not None:
         v0, i0 = state
-    cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params)
+    cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias))
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
     new_state = NeuronState(vT, iT) if neuron != _hip.NEURON_NONE else None
     return (out[0] if single else out), new_state

@@ -1,0 +1,112 @@
+"""Per-kernel timing with HIP events + the algorithmic work of every C-ABI launch.
+
+``bench.py`` installs a ``KernelProfiler`` for a few extra steps after its timed region: each
+``_hip.call`` is bracketed by two events recorded on the stream the kernel is launched on (torch's
+current stream), and its algorithmic FLOPs / bytes are derived from the call's own arguments with
+the work model of SURVEY section 8(d):
+
+* conv (fwd, dgrad, wgrad): ``2 * M * Cout * KH*KW*Cin`` FLOPs each (M = output pixels; dgrad and
+  wgrad each count as one forward); bytes = every operand read / written once;
+* fused norm+neuron scans: ``4 B`` per element per tensor the ideal fused kernel touches.
+
+Labels name the kernel template instance that ``csrc/conv.hip`` dispatches for the shape, so the
+rows can be matched with ``rocprofv3 --kernel-trace --stats`` output.
+"""
+
+from collections import defaultdict
+from typing import Dict
+
+import torch
+
+
+def _conv_label(name: str, a) -> str:
+    if name == "snn_conv2d_wgrad":
+        cin, cout = a[8], a[11]
+        vec = cin % 4 == 0 and cout % 4 == 0
+        return f"k_conv_wgrad<{'true' if vec else 'false'}>"
+    # fwd / dgrad share k_conv_gather<BN, WM, WN, DGRAD, VEC>
+    dgrad = name == "snn_conv2d_dgrad"
+    cin, cout = a[8], a[11]
+    oc, ic = (cin, cout) if dgrad else (cout, cin)
+    if oc <= 32:
+        tile = "32, 4, 1"
+    elif oc <= 64:
+        tile = "64, 2, 2"
+    else:
+        tile = "128, 2, 2"
+    return f"k_conv_gather<{tile}, {'true' if dgrad else 'false'}, {'true' if ic % 4 == 0 else 'false'}>"
+
+
+def work_of(name: str, a):
+    """-> (label, flops, bytes) for one launch, or (name, 0, 0) for bookkeeping kernels."""
+    if name in ("snn_conv2d_fwd", "snn_conv2d_dgrad"):
+        n, h, w, cin, ho, wo, cout, kh, kw = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]
+        flops = 2.0 * n * ho * wo * cout * kh * kw * cin
+        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
+        return _conv_label(name, a), flops, byts
+    if name == "snn_conv2d_wgrad":
+        n, h, w, cin, ho, wo, cout, kh, kw = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]
+        flops = 2.0 * n * ho * wo * cout * kh * kw * cin
+        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
+        return _conv_label(name, a), flops, byts
+    if name == "snn_affine_neuron_fwd":
+        neuron, T, M, C = a[0], a[12], a[13], a[14]
+        save = a[11] is not None
+        elems = float(T) * M * C
+        return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * (3 if save else 2)
+    if name == "snn_affine_neuron_bwd":
+        neuron, T, M, C = a[0], a[13], a[14], a[15]
+        elems = float(T) * M * C
+        tensors = 2 + (1 if a[3] is not None else 0) + (1 if a[12] is not None else 0)
+        return f"k_affine_neuron_bwd<{neuron}>", 16.0 * elems, 4.0 * elems * tensors
+    if name == "snn_bn_stats":
+        T, M, C = a[2], a[3], a[4]
+        return "k_bn_stats", 3.0 * T * M * C, 4.0 * T * M * C
+    if name == "snn_bn_bwd_apply":
+        T, M, C = a[8], a[9], a[10]
+        return "k_bn_bwd_apply", 4.0 * T * M * C, 12.0 * T * M * C
+    if name in ("snn_copy_channels", "snn_add_channels"):
+        M, C = a[4], a[5]
+        return "k_channels", 0.0, (8.0 if name == "snn_copy_channels" else 12.0) * M * C
+    if name == "snn_add":
+        return "k_add", float(a[3]), 12.0 * a[3]
+    if name in ("snn_nchw_to_nhwc", "snn_nhwc_to_nchw"):
+        n = float(a[2]) * a[3] * a[4] * a[5]
+        return "k_layout", 0.0, 8.0 * n
+    if name == "snn_adamax_step":
+        return "k_adamax", 8.0 * a[4], 28.0 * a[4]
+    return name, 0.0, 0.0
+
+
+class KernelProfiler:
+    """Install with ``_hip.PROFILER = KernelProfiler()``; call ``summary()`` after a device sync."""
+
+    def __init__(self):
+        self.records = []
+
+    def before(self, name, args):
+        label, flops, byts = work_of(name, args)
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        return (label, flops, byts, start, end)
+
+    def after(self, token):
+        token[4].record()
+        self.records.append(token)
+
+    def summary(self) -> Dict[str, dict]:
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for label, flops, byts, start, end in self.records:
+            row = agg[label]
+            row["calls"] += 1
+            row["ms"] += start.elapsed_time(end)
+            row["flops"] += flops
+            row["bytes"] += byts
+        for row in agg.values():
+            sec = max(row["ms"], 1e-9) * 1e-3
+            row["avg_us"] = 1e3 * row["ms"] / row["calls"]
+            row["tflops"] = row["flops"] / sec / 1e12
+            row["gbs"] = row["bytes"] / sec / 1e9
+        return dict(agg)
