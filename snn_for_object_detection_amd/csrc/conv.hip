@@ -30,34 +30,18 @@ constexpr int BK = 32;   // k elements per LDS stage
 constexpr int LDK = BK + 4;
 
 struct ConvGeom {
-    int64_t Mtot;      // img * OH * OW
+    int64_t Mtot;      // GEMM rows: img * OH * OW (FWD) or img * OHc * OWc (DGRAD, one stride-phase class)
     int IH, IW, IC;    // gathered tensor
     int OH, OW, OC;    // produced tensor
     int KH, KW, stride, pad;
     int64_t ldi, ldo;
-    int Ktot;          // KH*KW*IC
+    int Ktot;          // k extent of this launch: KH*KW*IC (FWD) or nkh*nkw*IC (DGRAD class)
+    int KtotFull;      // row length of the weight matrix: KH*KW*IC
+    // DGRAD only.  Output pixels (hi, wi) with hi % stride == ph, wi % stride == pw form one class; only the
+    // taps kh = kh0 + stride*jh (jh < nkh), kw = kw0 + stride*jw (jw < nkw) reach them, with source pixel
+    // iy = (hi + pad - kh0)/stride - jh (exact).  For stride 1 there is a single class with every tap.
+    int ph, pw, kh0, kw0, nkh, nkw, OHc, OWc;
 };
-
-template <bool DGRAD>
-__device__ __forceinline__ bool src_pixel(const ConvGeom& g, int y0, int x0, int kh, int kw, int& iy, int& ix) {
-    if (!DGRAD) {
-        iy = y0 + kh;
-        ix = x0 + kw;
-        return (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-    } else {
-        int ty = y0 - kh, tx = x0 - kw;
-        if (ty < 0 || tx < 0) return false;
-        if (g.stride == 1) {
-            iy = ty;
-            ix = tx;
-        } else {
-            if ((ty % g.stride) != 0 || (tx % g.stride) != 0) return false;
-            iy = ty / g.stride;
-            ix = tx / g.stride;
-        }
-        return iy < g.IH && ix < g.IW;
-    }
-}
 
 template <int BN, int WM, int WN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
@@ -66,8 +50,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    // two LDS stages: the MFMAs of stage k read buffer k&1 while the prefetched tile k+1 is written to the
+    // other buffer, so one barrier per k-step suffices
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -87,19 +73,37 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
         int64_t m = m0 + lr + 32 * j;
         a_ok[j] = m < g.Mtot;
         int64_t mm = a_ok[j] ? m : 0;
-        int ox = (int)(mm % g.OW);
-        int64_t t = mm / g.OW;
-        int oy = (int)(t % g.OH);
-        int64_t img = t / g.OH;
+        const int ow_ = DGRAD ? g.OWc : g.OW, oh_ = DGRAD ? g.OHc : g.OH;
+        int ox = (int)(mm % ow_);
+        int64_t t = mm / ow_;
+        int oy = (int)(t % oh_);
+        int64_t img = t / oh_;
         a_base[j] = img * g.IH * (int64_t)g.IW;
         if (!DGRAD) {
             a_y0[j] = oy * g.stride - g.pad;
             a_x0[j] = ox * g.stride - g.pad;
         } else {
-            a_y0[j] = oy + g.pad;
-            a_x0[j] = ox + g.pad;
+            a_y0[j] = (oy * g.stride + g.ph + g.pad - g.kh0) / g.stride;
+            a_x0[j] = (ox * g.stride + g.pw + g.pad - g.kw0) / g.stride;
         }
     }
+
+    // k index -> (source pixel offset, weight column)
+    auto decode_k = [&](int kk, int& dy, int& dx, int& c, int& wcol) {
+        int tap = kk / g.IC;
+        c = kk - tap * g.IC;
+        if (!DGRAD) {
+            int kh = tap / g.KW, kw = tap - kh * g.KW;
+            dy = kh;
+            dx = kw;
+            wcol = kk;
+        } else {
+            int jh = tap / g.nkw, jw = tap - jh * g.nkw;
+            dy = -jh;
+            dx = -jw;
+            wcol = ((g.kh0 + g.stride * jh) * g.KW + (g.kw0 + g.stride * jw)) * g.IC + c;
+        }
+    };
 
     f32x4 ra[4], rb[BROWS];
 
@@ -107,13 +111,13 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
         const int kk = k0 + kq;
         if (VEC) {
             const bool kin = kk < g.Ktot;
-            int tap = kk / g.IC, c = kk - tap * g.IC;
-            int kh = tap / g.KW, kw = tap - kh * g.KW;
+            int dy, dx, c, wcol;
+            decode_k(kin ? kk : 0, dy, dx, c, wcol);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int iy, ix;
+                const int iy = a_y0[j] + dy, ix = a_x0[j] + dx;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && a_ok[j] && src_pixel<DGRAD>(g, a_y0[j], a_x0[j], kh, kw, iy, ix))
+                if (kin && a_ok[j] && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
                     v = *reinterpret_cast<const f32x4*>(in + (a_base[j] + (int64_t)iy * g.IW + ix) * g.ldi + c);
                 ra[j] = v;
             }
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
             for (int j = 0; j < BROWS; ++j) {
                 int n = n0 + lr + 32 * j;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && n < g.OC) v = *reinterpret_cast<const f32x4*>(wk + (int64_t)n * g.Ktot + kk);
+                if (kin && n < g.OC) v = *reinterpret_cast<const f32x4*>(wk + (int64_t)n * g.KtotFull + wcol);
                 rb[j] = v;
             }
         } else {
@@ -129,29 +133,29 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
             for (int e = 0; e < 4; ++e) {
                 const int ke = kk + e;
                 const bool kin = ke < g.Ktot;
-                int tap = ke / g.IC, c = ke - tap * g.IC;
-                int kh = tap / g.KW, kw = tap - kh * g.KW;
+                int dy, dx, c, wcol;
+                decode_k(kin ? ke : 0, dy, dx, c, wcol);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    int iy, ix;
+                    const int iy = a_y0[j] + dy, ix = a_x0[j] + dx;
                     float v = 0.f;
-                    if (kin && a_ok[j] && src_pixel<DGRAD>(g, a_y0[j], a_x0[j], kh, kw, iy, ix))
+                    if (kin && a_ok[j] && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
                         v = in[(a_base[j] + (int64_t)iy * g.IW + ix) * g.ldi + c];
                     ra[j][e] = v;
                 }
 #pragma unroll
                 for (int j = 0; j < BROWS; ++j) {
                     int n = n0 + lr + 32 * j;
-                    rb[j][e] = (kin && n < g.OC) ? wk[(int64_t)n * g.Ktot + ke] : 0.f;
+                    rb[j][e] = (kin && n < g.OC) ? wk[(int64_t)n * g.KtotFull + wcol] : 0.f;
                 }
             }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[(lr + 32 * j) * LDK + kq]) = ra[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[buf][(lr + 32 * j) * LDK + kq]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * j) * LDK + kq]) = rb[j];
+        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(lr + 32 * j) * LDK + kq]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -163,21 +167,26 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     load_tiles(0);
-    store_tiles();
+    store_tiles(0);
     __syncthreads();
 
+    // Branch-free steady state (a tile past Ktot loads zeros and is never read): keeping the MFMA chain in
+    // one basic block lets the accumulators stay in their registers across iterations.
+    int cur = 0;
+#pragma unroll 1
     for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
-        const bool more = (k0 + BK) < g.Ktot;
-        if (more) load_tiles(k0 + BK);
+        load_tiles(k0 + BK);
+        const float* Ac = As[cur];
+        const float* Bc = Bs[cur];
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + r) * LDK + ks * 8 + 4 * h]);
+                a[i] = *reinterpret_cast<const f32x4*>(&Ac[((wm * TM + i) * 32 + r) * LDK + ks * 8 + 4 * h]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
+                b[j] = *reinterpret_cast<const f32x4*>(&Bc[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -186,11 +195,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
+        store_tiles(cur ^ 1);
         __syncthreads();
-        if (more) {
-            store_tiles();
-            __syncthreads();
-        }
+        cur ^= 1;
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -204,7 +211,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
             for (int e = 0; e < 16; ++e) {
                 const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.Mtot) {
-                    float* p = out + m * g.ldo + n;
+                    int64_t pix = m;
+                    if (DGRAD && g.stride > 1) {
+                        int b = (int)(m % g.OWc);
+                        int64_t t = m / g.OWc;
+                        int a = (int)(t % g.OHc);
+                        int64_t img = t / g.OHc;
+                        pix = (img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
+                    }
+                    float* p = out + pix * g.ldo + n;
                     float v = acc[i][j][e];
                     if (accumulate) v += *p;
                     *p = v;
@@ -214,8 +229,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
-constexpr int WB_M = 64;   // out channels per block
-constexpr int WB_N = 64;   // (tap, ci) columns per block
 constexpr int WB_K = 32;   // pixels per LDS stage
 
 struct WgradGeom {
@@ -224,33 +237,55 @@ struct WgradGeom {
     int64_t ldx, lddy;
     int Ktot;
     int64_t pix_per_split;
+    int tiles_m, tiles_n, splitk;
 };
 
-template <bool VEC>
+// Block tile (32*TM*WM) out-channels x (32*TN*WN) (tap,ci) columns; each wave owns TM x TN accumulators of
+// 32x32.  K = pixels, 32 per LDS stage; the decode pixel -> (image base, y0, x0) of a stage is done by 32
+// lanes and published through LDS one stage ahead.  Blocks of one pixel split are mapped to one XCD
+// (block ids congruent mod 8) so the dy / x tiles they share are served from that XCD's L2.
+template <int TM, int TN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ ws, WgradGeom g) {
-    __shared__ __attribute__((aligned(16))) float Ds[WB_K * WB_M];
-    __shared__ __attribute__((aligned(16))) float Xs[WB_K * WB_N];
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
+    constexpr int DG = BMc / 4, XG = BNk / 4;       // float4 groups per pixel row
+    constexpr int DP = kThreads / DG, XP = kThreads / XG;  // pixel rows per pass
+    constexpr int DJ = WB_K / DP, XJ = WB_K / XP;   // passes per stage
+    static_assert(DJ >= 1 && XJ >= 1, "tile too narrow");
+    __shared__ __attribute__((aligned(16))) float Ds[WB_K * BMc];
+    __shared__ __attribute__((aligned(16))) float Xs[WB_K * BNk];
+    __shared__ int Pinfo[2][WB_K][4];  // {image base pixel, y0, x0, valid}
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane_id & 31, h = lane_id >> 5;
 
-    const int co0 = blockIdx.x * WB_M;
-    const int kc0 = blockIdx.y * WB_N;
-    const int64_t p_lo = (int64_t)blockIdx.z * g.pix_per_split;
+    // ---- block -> (tile, split): blocks L, L+8, L+16, ... (one XCD) walk the tiles of one split
+    const int tiles = g.tiles_m * g.tiles_n;
+    int L = blockIdx.x, z, tile;
+    if (g.splitk % 8 == 0) {
+        z = (L % 8) + 8 * (L / (8 * tiles));
+        tile = (L / 8) % tiles;
+    } else {
+        z = L / tiles;
+        tile = L % tiles;
+    }
+    const int co0 = (tile % g.tiles_m) * BMc;
+    const int kc0 = (tile / g.tiles_m) * BNk;
+    const int64_t p_lo = (int64_t)z * g.pix_per_split;
     int64_t p_hi = p_lo + g.pix_per_split;
     if (p_hi > g.Mtot) p_hi = g.Mtot;
 
-    // loader: pixel rows pr + 16*j (j < 2), 4-wide column group cq
-    const int pr = tid >> 4, cq = (tid & 15) * 4;
-    // the gathered column (tap, ci) of this thread never changes
+    // ---- loader geometry
+    const int d_cq = (tid % DG) * 4, d_pr = tid / DG;
+    const int x_cq = (tid % XG) * 4, x_pr = tid / XG;
     int x_kh[4], x_kw[4], x_ci[4];
     bool x_ok[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        int kc = kc0 + cq + e;
+        int kc = kc0 + x_cq + e;
         x_ok[e] = kc < g.Ktot;
         int kcc = x_ok[e] ? kc : 0;
         int tap = kcc / g.Cin;
@@ -258,86 +293,122 @@ __global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict
         x_kh[e] = tap / g.KW;
         x_kw[e] = tap - x_kh[e] * g.KW;
     }
-    const bool d_ok = VEC ? (co0 + cq < g.Cout) : true;
+    const bool d_ok = (co0 + d_cq) < g.Cout;
 
-    f32x4 rd[2], rx[2];
-    auto load_tiles = [&](int64_t p0) {
+    auto decode = [&](int64_t p0, int slot) {
+        if (tid < WB_K) {
+            const int64_t p = p0 + tid;
+            int ok = p < p_hi ? 1 : 0;
+            int64_t pp = ok ? p : 0;
+            int ox = (int)(pp % g.Wo);
+            int64_t t = pp / g.Wo;
+            int oy = (int)(t % g.Ho);
+            int img = (int)(t / g.Ho);
+            Pinfo[slot][tid][0] = img * g.H * g.W;
+            Pinfo[slot][tid][1] = oy * g.stride - g.pad;
+            Pinfo[slot][tid][2] = ox * g.stride - g.pad;
+            Pinfo[slot][tid][3] = ok;
+        }
+    };
+
+    f32x4 rd[DJ], rx[XJ];
+    auto load_tiles = [&](int64_t p0, int slot) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t p = p0 + pr + 16 * j;
-            f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < DJ; ++j) {
+            const int row = d_pr + DP * j;
+            const int64_t p = p0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (p < p_hi) {
-                int ox = (int)(p % g.Wo);
-                int64_t t = p / g.Wo;
-                int oy = (int)(t % g.Ho);
-                int64_t img = t / g.Ho;
-                const int y0 = oy * g.stride - g.pad, x0 = ox * g.stride - g.pad;
-                const int64_t ibase = img * g.H * (int64_t)g.W;
                 if (VEC) {
-                    if (d_ok) dv = *reinterpret_cast<const f32x4*>(dy + p * g.lddy + co0 + cq);
-                    if (x_ok[0]) {
-                        int iy = y0 + x_kh[0], ix = x0 + x_kw[0];
-                        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                            xv = *reinterpret_cast<const f32x4*>(x + (ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[0]);
-                    }
+                    if (d_ok) v = *reinterpret_cast<const f32x4*>(dy + p * g.lddy + co0 + d_cq);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co0 + cq + e < g.Cout) dv[e] = dy[p * g.lddy + co0 + cq + e];
-                        if (x_ok[e]) {
-                            int iy = y0 + x_kh[e], ix = x0 + x_kw[e];
-                            if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                                xv[e] = x[(ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[e]];
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (co0 + d_cq + e < g.Cout) v[e] = dy[p * g.lddy + co0 + d_cq + e];
                 }
             }
-            rd[j] = dv;
-            rx[j] = xv;
+            rd[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int row = x_pr + XP * j;
+            const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
+            const bool ok = Pinfo[slot][row][3] != 0;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                const int iy = y0 + x_kh[0], ix = x0 + x_kw[0];
+                if (ok && x_ok[0] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                    v = *reinterpret_cast<const f32x4*>(x + ((int64_t)ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[0]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int iy = y0 + x_kh[e], ix = x0 + x_kw[e];
+                    if (ok && x_ok[e] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                        v[e] = x[((int64_t)ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[e]];
+                }
+            }
+            rx[j] = v;
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<f32x4*>(&Ds[(pr + 16 * j) * WB_M + cq]) = rd[j];
-            *reinterpret_cast<f32x4*>(&Xs[(pr + 16 * j) * WB_N + cq]) = rx[j];
-        }
+        for (int j = 0; j < DJ; ++j) *reinterpret_cast<f32x4*>(&Ds[(d_pr + DP * j) * BMc + d_cq]) = rd[j];
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) *reinterpret_cast<f32x4*>(&Xs[(x_pr + XP * j) * BNk + x_cq]) = rx[j];
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (p_lo < p_hi) {
-        load_tiles(p_lo);
+    decode(p_lo, 0);
+    __syncthreads();
+    load_tiles(p_lo, 0);
+    decode(p_lo + WB_K, 1);
+    store_tiles();
+    __syncthreads();
+
+    int slot = 1;
+#pragma unroll 1
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += WB_K) {
+        load_tiles(p0 + WB_K, slot);        // rows past p_hi load zeros
+        decode(p0 + 2 * WB_K, slot ^ 1);    // slot^1 was last read one iteration ago, before a barrier
+#pragma unroll
+        for (int ks = 0; ks < WB_K / 2; ++ks) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ds[(ks * 2 + h) * BMc + (wm * TM + i) * 32 + r];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[(ks * 2 + h) * BNk + (wn * TN + j) * 32 + r];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
         store_tiles();
         __syncthreads();
-        for (int64_t p0 = p_lo; p0 < p_hi; p0 += WB_K) {
-            const bool more = (p0 + WB_K) < p_hi;
-            if (more) load_tiles(p0 + WB_K);
-#pragma unroll
-            for (int ks = 0; ks < WB_K / 2; ++ks) {
-                float a = Ds[(ks * 2 + h) * WB_M + wm * 32 + r];
-                float b = Xs[(ks * 2 + h) * WB_N + wn * 32 + r];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
-            __syncthreads();
-            if (more) {
-                store_tiles();
-                __syncthreads();
-            }
-        }
+        slot ^= 1;
     }
 
-    float* slab = ws + (int64_t)blockIdx.z * g.Cout * (int64_t)g.Ktot;
-    const int kc = kc0 + wn * 32 + r;
-    if (kc < g.Ktot) {
+    float* slab = ws + (int64_t)z * g.Cout * (int64_t)g.Ktot;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (co < g.Cout) slab[(int64_t)co * g.Ktot + kc] = acc[e];
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int kc = kc0 + (wn * TN + j) * 32 + r;
+            if (kc >= g.Ktot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < g.Cout) slab[(int64_t)co * g.Ktot + kc] = acc[i][j][e];
+            }
         }
-    }
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splitk,
@@ -403,7 +474,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     g.OH = Ho; g.OW = Wo; g.OC = Cout;
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldi = ldx; g.ldo = ldy;
-    g.Ktot = KH * KW * Cin;
+    g.Ktot = g.KtotFull = KH * KW * Cin;
+    g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
     return launch_gather<false>(x, w, y, g, accumulate, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
@@ -414,26 +486,61 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(lddy >= Cout && lddx >= Cin, "snn_conv2d_dgrad: pixel stride smaller than channel count");
     ConvGeom g;
-    g.Mtot = N * H * (int64_t)W;      // one GEMM row per INPUT pixel
     g.IH = Ho; g.IW = Wo; g.IC = Cout;  // gathered tensor is dy
-    g.OH = H; g.OW = W; g.OC = Cin;
+    g.OH = H; g.OW = W; g.OC = Cin;     // one GEMM row per INPUT pixel
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldi = lddy; g.ldo = lddx;
-    g.Ktot = KH * KW * Cout;
-    return launch_gather<true>(dy, wt, dx, g, accumulate, (hipStream_t)stream, "snn_conv2d_dgrad");
+    g.KtotFull = KH * KW * Cout;
+    // one launch per stride phase: each class multiplies only the taps that can reach it
+    for (int ph = 0; ph < stride && ph < H; ++ph)
+        for (int pw = 0; pw < stride && pw < W; ++pw) {
+            g.ph = ph; g.pw = pw;
+            g.kh0 = (ph + pad) % stride; g.kw0 = (pw + pad) % stride;
+            g.nkh = g.kh0 < KH ? (KH - g.kh0 + stride - 1) / stride : 0;
+            g.nkw = g.kw0 < KW ? (KW - g.kw0 + stride - 1) / stride : 0;
+            g.OHc = (H - ph + stride - 1) / stride;
+            g.OWc = (W - pw + stride - 1) / stride;
+            g.Mtot = N * g.OHc * (int64_t)g.OWc;
+            g.Ktot = g.nkh * g.nkw * Cout;
+            int rc = launch_gather<true>(dy, wt, dx, g, accumulate, (hipStream_t)stream, "snn_conv2d_dgrad");
+            if (rc) return rc;
+        }
+    return 0;
 }
+
+namespace {
+struct WgradTile { int bm, bn, id; };
+// candidate block tiles (out-channels x (tap,ci) columns); pick the one that wastes the least MFMA work on
+// padding, larger tiles first on ties (fewer LDS / L2 bytes per FLOP)
+static WgradTile wgrad_tile(int Cout, int Ktot) {
+    static const WgradTile cand[] = {{128, 128, 0}, {64, 256, 1}, {32, 256, 2}, {128, 64, 3}, {64, 64, 4}, {32, 128, 5}};
+    WgradTile best = cand[0];
+    double best_eff = -1.0;
+    for (const WgradTile& c : cand) {
+        double padded = (double)(snn_ceil_div(Cout, c.bm) * c.bm) * (double)(snn_ceil_div(Ktot, c.bn) * c.bn);
+        double eff = (double)Cout * Ktot / padded;
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = c;
+        }
+    }
+    return best;
+}
+}  // namespace
 
 extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
     const int64_t M = N * Ho * (int64_t)Wo;
     const int64_t Ktot = (int64_t)KH * KW * Cin;
-    const int64_t tiles = snn_ceil_div(Cout, WB_M) * snn_ceil_div(Ktot, WB_N);
-    int64_t s = snn_ceil_div(4 * SNN_NUM_CU, tiles);                 // ~4 blocks per CU
+    const WgradTile t = wgrad_tile(Cout, (int)Ktot);
+    const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
+    int64_t s = snn_ceil_div(3 * SNN_NUM_CU, tiles);                  // ~3 blocks per CU
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
     if (s > max_by_work) s = max_by_work;
     if (s > max_by_mem) s = max_by_mem;
-    if (s > 65535) s = 65535;
+    if (s > 8) s = (s + 7) / 8 * 8;  // whole groups of 8 splits: one split per XCD at a time
+    if (s > 32768) s = 32768;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -444,7 +551,8 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     SNN_REQUIRE(x && dy && dw && workspace, "snn_conv2d_wgrad: null pointer");
     if (check_conv_shape("snn_conv2d_wgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && lddy >= Cout, "snn_conv2d_wgrad: pixel stride smaller than channel count");
-    SNN_REQUIRE(splitk >= 1 && splitk <= 65535, "snn_conv2d_wgrad: bad splitk %d", splitk);
+    SNN_REQUIRE(splitk >= 1 && splitk <= 32768, "snn_conv2d_wgrad: bad splitk %d", splitk);
+    SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL, "snn_conv2d_wgrad: more than 2^31 input pixels");
     WgradGeom g;
     g.Mtot = N * Ho * (int64_t)Wo;
     g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout;
@@ -452,12 +560,32 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
     g.pix_per_split = snn_ceil_div(snn_ceil_div(g.Mtot, splitk), WB_K) * WB_K;
+    const WgradTile t = wgrad_tile(Cout, g.Ktot);
+    g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
+    g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
+    g.splitk = splitk;
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);
-    dim3 grid((unsigned)snn_ceil_div(Cout, WB_M), (unsigned)snn_ceil_div(g.Ktot, WB_N), (unsigned)splitk);
+    const int64_t nblocks = (int64_t)g.tiles_m * g.tiles_n * splitk;
+    SNN_REQUIRE(nblocks <= 0x7fffffff, "snn_conv2d_wgrad: grid too large");
+    dim3 grid((unsigned)nblocks);
     hipStream_t st = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL(k_conv_wgrad<true>, grid, dim3(kThreads), 0, st, x, dy, workspace, g);
-    else hipLaunchKernelGGL(k_conv_wgrad<false>, grid, dim3(kThreads), 0, st, x, dy, workspace, g);
+#define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
+    do {                                                                                                       \
+        if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
+                                    dy, workspace, g);                                                         \
+        else hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, false>), grid, dim3(kThreads), 0, st, x, dy, \
+                                workspace, g);                                                                 \
+    } while (0)
+    switch (t.id) {
+        case 0: SNN_WGRAD_LAUNCH(2, 2, 2, 2); break;   // 128 x 128
+        case 1: SNN_WGRAD_LAUNCH(2, 2, 1, 4); break;   //  64 x 256
+        case 2: SNN_WGRAD_LAUNCH(1, 2, 1, 4); break;   //  32 x 256
+        case 3: SNN_WGRAD_LAUNCH(2, 1, 2, 2); break;   // 128 x  64
+        case 4: SNN_WGRAD_LAUNCH(1, 1, 2, 2); break;   //  64 x  64
+        default: SNN_WGRAD_LAUNCH(1, 1, 1, 4); break;  //  32 x 128
+    }
+#undef SNN_WGRAD_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
     const int64_t n = (int64_t)Cout * g.Ktot;
     int64_t blocks = snn_ceil_div(n, kThreads);

@@ -230,119 +230,151 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 
 // ------------------------------------------------------------------------------------------
 // Backward (reverse-time) scan with per-(t,c) partial sums for the BatchNorm backward.
-// grid = (GX pixel groups, GY channel blocks).  LDS holds red[T][cb][2] fp32 block sums.
+// grid = (GX pixel groups, GY channel blocks).  A thread owns NP pixels x VEC channels; per timestep it
+// sums its NP contributions in registers, lanes of a wave that share channels combine with xor-shuffles,
+// and one lane per (wave, channel) adds into that wave's private LDS slab red[wave][T][cb][2] (plain
+// read-modify-write, fixed order).  Waves and blocks are combined in fixed order afterwards, so the
+// BatchNorm gradients are bitwise reproducible.  (Channel counts whose per-block group count is not a
+// power of two fall back to LDS float atomics on one shared slab.)
 // ------------------------------------------------------------------------------------------
+constexpr int kBwdNP = 4;
+constexpr int kWaves = kThreads / 64;
+
 struct BwdPlan {
-    int vec, cvb, gy, gx;
+    int vec, cvb, gy, gx, mode;  // mode 0: no sums, 1: ordered (shuffle + per-wave slabs), 2: LDS atomics
     size_t lds_bytes;
 };
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     BwdPlan pl;
     pl.vec = (C % 4 == 0) ? 4 : 1;
     int cv = C / pl.vec;
     int cvb = cv < kThreads ? cv : kThreads;
+    pl.mode = 0;
+    pl.lds_bytes = 0;
     if (with_sums) {
-        // LDS budget 64 KiB: T * cb * 2 floats
-        int64_t max_cb = (64 * 1024) / ((int64_t)T * 8);
-        int max_cvb = (int)(max_cb / pl.vec);
+        const bool ordered = is_pow2(cvb) || cvb >= 64;
+        pl.mode = ordered ? 1 : 2;
+        const int slabs = ordered ? kWaves : 1;
+        // LDS budget 64 KiB: slabs * T * cb * 2 floats
+        int64_t max_cvb = (64 * 1024) / ((int64_t)slabs * T * 8 * pl.vec);
         if (max_cvb < 1) max_cvb = 1;
-        if (cvb > max_cvb) cvb = max_cvb;
+        if (cvb > max_cvb) {
+            cvb = (int)max_cvb;
+            if (ordered) {  // keep a power of two
+                int p2 = 1;
+                while (p2 * 2 <= cvb) p2 *= 2;
+                cvb = p2;
+            }
+        }
+        pl.lds_bytes = (size_t)slabs * T * cvb * pl.vec * 2 * sizeof(float);
     }
     pl.cvb = cvb;
     pl.gy = (int)snn_ceil_div(cv, cvb);
     int P = kThreads / cvb;
-    int64_t gx = snn_ceil_div(M, (int64_t)P);
-    int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;
+    int64_t gx = snn_ceil_div(M, (int64_t)P * kBwdNP);
+    int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;  // 64 KiB of LDS per block -> 2 blocks per CU
     cap = cap / pl.gy;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     pl.gx = (int)gx;
-    pl.lds_bytes = with_sums ? (size_t)T * cvb * pl.vec * 2 * sizeof(float) : 0;
     return pl;
 }
 
-template <int NEURON, int VEC>
+template <int NEURON, int VEC, int MODE>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ scale,
     float* __restrict__ gx, float* __restrict__ g_v0, float* __restrict__ g_i0, double* __restrict__ sums, int T,
     int64_t M, int C, int cvb, snn_neuron_params p) {
     typedef typename Vec<VEC>::type V;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [T][cvb*VEC][2]
+    constexpr int NP = kBwdNP;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // MODE 1: [wave][T][cb][2]; MODE 2: [T][cb][2]
     const int cv = C / VEC;
     const int P = kThreads / cvb;
     const int tid = threadIdx.x;
     const int cgl = tid % cvb, ps = tid / cvb;
     const int cg = blockIdx.y * cvb + cgl;
     const int cb = cvb * VEC;
-    const bool active = (ps < P) && (cg < cv);
-    const int c = cg * VEC;
-    if (sums) {
-        for (int k = tid; k < T * cb * 2; k += kThreads) red[k] = 0.0f;
+    const bool lane_ok = (ps < P) && (cg < cv);
+    const int c = lane_ok ? cg * VEC : 0;
+    const int wave = tid >> 6;
+    if (MODE != 0) {
+        const int n = (MODE == 1 ? kWaves : 1) * T * cb * 2;
+        for (int k = tid; k < n; k += kThreads) red[k] = 0.0f;
         __syncthreads();
     }
-    if (active) {
-        const float one_m_cmem = 1.0f - p.c_mem;
-        const float one_p_csyn = 1.0f + p.c_syn;
-        for (int64_t m = (int64_t)blockIdx.x * P + ps; m < M; m += (int64_t)gridDim.x * P) {
-            V gv, gi;
-            if (NEURON != SNN_NEURON_NONE) {
-                if (g_vT) gv = Vec<VEC>::load(g_vT + m * C + c);
-                else {
+    const float one_m_cmem = 1.0f - p.c_mem;
+    const float one_p_csyn = 1.0f + p.c_syn;
+    for (int64_t mb = (int64_t)blockIdx.x * P * NP; mb < M; mb += (int64_t)gridDim.x * P * NP) {
+        int64_t mq[NP];
+        bool ok[NP];
+        V gv[NP], gi[NP];
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) lane<VEC>(gv, j) = 0.0f;
-                }
-                if (g_iT) gi = Vec<VEC>::load(g_iT + m * C + c);
-                else {
+        for (int q = 0; q < NP; ++q) {
+            mq[q] = mb + (int64_t)q * P + ps;
+            ok[q] = lane_ok && mq[q] < M;
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) lane<VEC>(gi, j) = 0.0f;
+            for (int j = 0; j < VEC; ++j) lane<VEC>(gv[q], j) = lane<VEC>(gi[q], j) = 0.0f;
+            if (NEURON != SNN_NEURON_NONE && ok[q]) {
+                if (g_vT) gv[q] = Vec<VEC>::load(g_vT + mq[q] * C + c);
+                if (g_iT) gi[q] = Vec<VEC>::load(g_iT + mq[q] * C + c);
+            }
+        }
+        for (int t = T - 1; t >= 0; --t) {
+            float s1[VEC], s2[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
+            V go[NP], st[NP], yv[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {  // issue every load of this timestep first
+                if (ok[q]) {
+                    const int64_t row = (int64_t)t * M + mq[q];
+                    go[q] = Vec<VEC>::load(g_out + row * ldg + c);
+                    if (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH) st[q] = Vec<VEC>::load(state + row * C + c);
+                    if (MODE != 0) yv[q] = Vec<VEC>::load(y + row * ldy + c);
                 }
             }
-            for (int t = T - 1; t >= 0; --t) {
-                const int64_t row = (int64_t)t * M + m;
-                V go = Vec<VEC>::load(g_out + row * ldg + c);
-                V st;
-                if (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH) st = Vec<VEC>::load(state + row * C + c);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (!ok[q]) continue;
+                const int64_t row = (int64_t)t * M + mq[q];
                 V g;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    float goj = lane<VEC>(go, j);
+                    float goj = lane<VEC>(go[q], j);
                     if (NEURON == SNN_NEURON_NONE) {
                         lane<VEC>(g, j) = goj;
                     } else if (NEURON == SNN_NEURON_LIF) {
-                        float vd = lane<VEC>(st, j);
+                        float vd = lane<VEC>(st[q], j);
                         float u = vd - p.v_th;
                         float z = (u > 0.0f) ? 1.0f : 0.0f;
                         float den = p.alpha * fabsf(u) + 1.0f;
                         float sg = 1.0f / (den * den);
-                        float gvj = lane<VEC>(gv, j);
+                        float gvj = lane<VEC>(gv[q], j);
                         float gz = goj + gvj * (p.v_reset - vd);
                         float g_vd = gvj * (1.0f - z) + gz * sg;
-                        float g_in = p.c_mem * g_vd + lane<VEC>(gi, j) * one_p_csyn;
-                        lane<VEC>(gv, j) = g_vd * one_m_cmem;
-                        lane<VEC>(gi, j) = g_in;
+                        float g_in = p.c_mem * g_vd + lane<VEC>(gi[q], j) * one_p_csyn;
+                        lane<VEC>(gv[q], j) = g_vd * one_m_cmem;
+                        lane<VEC>(gi[q], j) = g_in;
                         lane<VEC>(g, j) = g_in;
                     } else {
                         float d = 1.0f;
                         if (NEURON == SNN_NEURON_LI_TANH) {
-                            float o = lane<VEC>(st, j);
+                            float o = lane<VEC>(st[q], j);
                             d = 1.0f - o * o;
                         }
-                        float g_vn = goj * d + lane<VEC>(gv, j);
-                        float g_in = p.c_mem * g_vn + lane<VEC>(gi, j) * one_p_csyn;
-                        lane<VEC>(gv, j) = g_vn * one_m_cmem;
-                        lane<VEC>(gi, j) = g_in;
+                        float g_vn = goj * d + lane<VEC>(gv[q], j);
+                        float g_in = p.c_mem * g_vn + lane<VEC>(gi[q], j) * one_p_csyn;
+                        lane<VEC>(gv[q], j) = g_vn * one_m_cmem;
+                        lane<VEC>(gi[q], j) = g_in;
                         lane<VEC>(g, j) = g_in;
                     }
-                }
-                if (sums) {
-                    V yv = Vec<VEC>::load(y + row * ldy + c);
-                    float* r = red + ((int64_t)t * cb + cgl * VEC) * 2;
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        atomicAdd(r + j * 2 + 0, lane<VEC>(g, j));
-                        atomicAdd(r + j * 2 + 1, lane<VEC>(g, j) * lane<VEC>(yv, j));
+                    if (MODE != 0) {
+                        s1[j] += lane<VEC>(g, j);
+                        s2[j] += lane<VEC>(g, j) * lane<VEC>(yv[q], j);
                     }
                 }
                 if (scale) {
@@ -352,13 +384,45 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 }
                 Vec<VEC>::store(gx + row * C + c, g);
             }
-            if (NEURON != SNN_NEURON_NONE) {
-                if (g_v0) Vec<VEC>::store(g_v0 + m * C + c, gv);
-                if (g_i0) Vec<VEC>::store(g_i0 + m * C + c, gi);
+            if (MODE == 1) {
+                // lanes l and l ^ stride (stride a multiple of cvb) hold the same channels
+                if (cvb < 64) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        for (int stride = cvb; stride < 64; stride <<= 1) {
+                            s1[j] += __shfl_xor(s1[j], stride, 64);
+                            s2[j] += __shfl_xor(s2[j], stride, 64);
+                        }
+                }
+                if ((cvb >= 64 || (tid & 63) < cvb) && lane_ok) {
+                    float* r = red + (((int64_t)wave * T + t) * cb + cgl * VEC) * 2;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        r[j * 2 + 0] += s1[j];
+                        r[j * 2 + 1] += s2[j];
+                    }
+                }
+            } else if (MODE == 2) {
+                if (lane_ok) {
+                    float* r = red + ((int64_t)t * cb + cgl * VEC) * 2;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        atomicAdd(r + j * 2 + 0, s1[j]);
+                        atomicAdd(r + j * 2 + 1, s2[j]);
+                    }
+                }
+            }
+        }
+        if (NEURON != SNN_NEURON_NONE) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (!ok[q]) continue;
+                if (g_v0) Vec<VEC>::store(g_v0 + mq[q] * C + c, gv[q]);
+                if (g_i0) Vec<VEC>::store(g_i0 + mq[q] * C + c, gi[q]);
             }
         }
     }
-    if (sums) {
+    if (MODE != 0) {
         __syncthreads();
         // sums[bx][t][c][2]
         double* dst = sums + (int64_t)blockIdx.x * T * C * 2;
@@ -366,27 +430,49 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
         for (int k = tid; k < T * cb; k += kThreads) {
             int t = k / cb, cl = k % cb;
             if (c_lo + cl < C) {
-                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = (double)red[k * 2 + 0];
-                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = (double)red[k * 2 + 1];
+                float a = 0.0f, b = 0.0f;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) {
+                        a += red[((int64_t)w * T * cb + k) * 2 + 0];
+                        b += red[((int64_t)w * T * cb + k) * 2 + 1];
+                    }
+                } else {
+                    a = red[k * 2 + 0];
+                    b = red[k * 2 + 1];
+                }
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = (double)a;
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = (double)b;
             }
         }
     }
 }
 
-// reduce block partials -> per (t,c) S1 = sum gx, S2 = sum gx*y (kept in block 0's slot), emit coefficients
-__global__ void k_bn_bwd_finalize(double* __restrict__ sums, int gx_blocks, int T, int64_t M, int C,
-                                  const float* __restrict__ gamma, const float* __restrict__ mean,
-                                  const float* __restrict__ invstd, float* __restrict__ coefA,
-                                  float* __restrict__ coefB, float* __restrict__ coefC) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * C) return;
-    int c = idx % C;
+// reduce block partials -> per (t,c) S1 = sum gx, S2 = sum gx*xhat (kept in block 0's slot), emit coefficients.
+// 32 lanes per (t,c): lane k sums blocks k, k+32, ... then a fixed xor tree combines the lanes.
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(double* __restrict__ sums, int gx_blocks, int T, int64_t M,
+                                                         int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ coefA,
+                                                         float* __restrict__ coefB, float* __restrict__ coefC) {
+    const int sub = threadIdx.x & 31;
+    const int idx = blockIdx.x * (blockDim.x / 32) + (threadIdx.x >> 5);
+    const bool live = idx < T * C;
     double s1 = 0.0, sy = 0.0;
-    for (int b = 0; b < gx_blocks; ++b) {
-        const double* src = sums + ((int64_t)b * T * C + idx) * 2;
-        s1 += src[0];
-        sy += src[1];
+    if (live) {
+        for (int b = sub; b < gx_blocks; b += 32) {
+            const double* src = sums + ((int64_t)b * T * C + idx) * 2;
+            s1 += src[0];
+            sy += src[1];
+        }
     }
+    for (int stride = 16; stride >= 1; stride >>= 1) {
+        s1 += __shfl_xor(s1, stride, 64);
+        sy += __shfl_xor(sy, stride, 64);
+    }
+    __syncthreads();  // every partial of this block's (t,c) pairs has been read before slot 0 is rewritten
+    if (!live || sub != 0) return;
+    const int c = idx % C;
     double mu = (double)mean[idx], is = (double)invstd[idx];
     double s2 = is * (sy - mu * s1);  // sum gx * xhat
     sums[(int64_t)idx * 2 + 0] = s1;
@@ -540,16 +626,21 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
     return (size_t)pl.gx * T * C * 2;
 }
 
-#define SNN_DISPATCH_BWD(NEURON)                                                                                   \
-    do {                                                                                                           \
-        if (pl.vec == 4)                                                                                           \
-            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 4>), grid, dim3(kThreads), pl.lds_bytes,                \
-                               (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0,   \
-                               sums, T, M, C, pl.cvb, *p);                                                          \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 1>), grid, dim3(kThreads), pl.lds_bytes,                \
-                               (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0,   \
-                               sums, T, M, C, pl.cvb, *p);                                                          \
+#define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                                                                      \
+    hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_>), grid, dim3(kThreads), pl.lds_bytes,           \
+                       (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0, sums,  \
+                       T, M, C, pl.cvb, *p)
+#define SNN_DISPATCH_BWD(NEURON)                                  \
+    do {                                                          \
+        if (pl.vec == 4) {                                        \
+            if (pl.mode == 0) SNN_LAUNCH_BWD(NEURON, 4, 0);       \
+            else if (pl.mode == 1) SNN_LAUNCH_BWD(NEURON, 4, 1);  \
+            else SNN_LAUNCH_BWD(NEURON, 4, 2);                    \
+        } else {                                                  \
+            if (pl.mode == 0) SNN_LAUNCH_BWD(NEURON, 1, 0);       \
+            else if (pl.mode == 1) SNN_LAUNCH_BWD(NEURON, 1, 1);  \
+            else SNN_LAUNCH_BWD(NEURON, 1, 2);                    \
+        }                                                         \
     } while (0)
 
 extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state, const float* y,
@@ -588,7 +679,7 @@ extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const 
     SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_bwd_finalize: bad shape");
     BwdPlan pl = bwd_plan(T, M, C, true);
     int n = T * C;
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, M,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, M,
                        C, gamma, mean, invstd, coefA, coefB, coefC);
     SNN_CHECK_LAUNCH("snn_bn_bwd_finalize");
     if (dgamma || dbias) {

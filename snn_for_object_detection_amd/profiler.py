@@ -21,9 +21,7 @@ import torch
 
 def _conv_label(name: str, a) -> str:
     if name == "snn_conv2d_wgrad":
-        cin, cout = a[8], a[11]
-        vec = cin % 4 == 0 and cout % 4 == 0
-        return f"k_conv_wgrad<{'true' if vec else 'false'}>"
+        return "k_conv_wgrad"  # all tile variants of the weight-gradient kernel (+ its ordered reduce)
     # fwd / dgrad share k_conv_gather<BN, WM, WN, DGRAD, VEC>
     dgrad = name == "snn_conv2d_dgrad"
     cin, cout = a[8], a[11]

@@ -33,6 +33,9 @@ CONV_CASES = [
     (1, 1, 8, 13, 9, 12, 5, 1),       # k=5 (README example nets)
     (1, 1, 4, 16, 15, 8, 7, 2),       # k=7 stride 2
     (3, 2, 64, 30, 38, 64, 3, 1),     # several 128-pixel tiles, K loop of 18 stages
+    (1, 1, 8, 9, 7, 16, 1, 2),        # k=1 stride 2: three of the four dgrad stride-phase classes have no tap
+    (1, 2, 4, 11, 10, 8, 3, 3),       # stride 3
+    (2, 1, 128, 15, 19, 256, 3, 2),   # neck downsampling conv shape (odd sizes)
 ]
 
 
@@ -195,6 +198,29 @@ def test_lif_state_carry_equals_sequence(HF):
     (zr * g.cpu()).sum().backward()
     assert torch.equal(z_seq.cpu(), zr)
     assert rel_err(xs.grad, xc.grad) < 1e-6
+
+
+def test_bn_backward_is_bitwise_reproducible(HF):
+    """ordered block / wave reduction of the BatchNorm sums: two runs give identical bits."""
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(21)
+    for C in (32, 64, 24):   # 24 -> 6 channel groups: the non-power-of-two fallback is exempt
+        y = (2 * torch.randn(6, 3, C, 11, 13)).cuda()
+        g = torch.randn(6, 3, C, 11, 13).cuda()
+        res = []
+        for _ in range(2):
+            bn = HipBatchNorm2d(C).cuda()
+            yd = y.clone().requires_grad_()
+            z, _ = HF.affine_neuron(yd, _hip.NEURON_LIF, None, bn=bn)
+            (z * g).sum().backward()
+            res.append((yd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+        if C != 24:
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+        else:
+            for a, b in zip(*res):
+                assert rel_err(a, b) < 1e-5
 
 
 def test_standalone_norm_matches_batchnorm(HF):
