@@ -28,6 +28,13 @@ constexpr int kThreads = 256;
 constexpr int BM = 128;  // output pixels per block
 constexpr int BK = 32;   // k elements per LDS stage
 constexpr int LDK = BK + 4;
+#ifndef SNN_CONV_LDS_STAGES
+#define SNN_CONV_LDS_STAGES 1
+#endif
+#ifndef SNN_CONV_MIN_WAVES
+#define SNN_CONV_MIN_WAVES 3
+#endif
+constexpr int NSTAGE = SNN_CONV_LDS_STAGES;
 
 struct ConvGeom {
     int64_t Mtot;      // GEMM rows: img * OH * OW (FWD) or img * OHc * OWc (DGRAD, one stride-phase class)
@@ -44,7 +51,7 @@ struct ConvGeom {
 };
 
 template <int BN, int WM, int WN, bool DGRAD, bool VEC>
-__global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
+__global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g, int accumulate) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -52,8 +59,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
     static_assert(WM * WN == 4, "4 waves");
     // two LDS stages: the MFMAs of stage k read buffer k&1 while the prefetched tile k+1 is written to the
     // other buffer, so one barrier per k-step suffices
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[NSTAGE][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -110,23 +117,26 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
     auto load_tiles = [&](int k0) {
         const int kk = k0 + kq;
         if (VEC) {
+            // Branch-free: every lane always loads from a clamped (valid) address and masks the value afterwards,
+            // so the whole k-step stays one basic block and the scheduler can interleave these loads with MFMAs.
             const bool kin = kk < g.Ktot;
             int dy, dx, c, wcol;
-            decode_k(kin ? kk : 0, dy, dx, c, wcol);
+            decode_k(kin ? kk : g.Ktot - 4, dy, dx, c, wcol);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int iy = a_y0[j] + dy, ix = a_x0[j] + dx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && a_ok[j] && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
-                    v = *reinterpret_cast<const f32x4*>(in + (a_base[j] + (int64_t)iy * g.IW + ix) * g.ldi + c);
-                ra[j] = v;
+                const bool ok = kin & a_ok[j] & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                const int iyc = min(max(iy, 0), g.IH - 1), ixc = min(max(ix, 0), g.IW - 1);
+                f32x4 v = *reinterpret_cast<const f32x4*>(in + (a_base[j] + (int64_t)(iyc * g.IW + ixc)) * g.ldi + c);
+                ra[j] = ok ? v : zero;
             }
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
-                int n = n0 + lr + 32 * j;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && n < g.OC) v = *reinterpret_cast<const f32x4*>(wk + (int64_t)n * g.KtotFull + wcol);
-                rb[j] = v;
+                const int n = n0 + lr + 32 * j;
+                const int nc = min(n, g.OC - 1);
+                f32x4 v = *reinterpret_cast<const f32x4*>(wk + (int64_t)nc * g.KtotFull + wcol);
+                rb[j] = (kin & (n < g.OC)) ? v : zero;
             }
         } else {
 #pragma unroll
@@ -166,8 +176,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
+    if (g.Ktot > 0) {  // a dgrad stride-phase class may have no tap at all: its pixels are plain zeros
+        load_tiles(0);
+        store_tiles(0);
+    }
     __syncthreads();
 
     // Branch-free steady state (a tile past Ktot loads zeros and is never read): keeping the MFMA chain in
@@ -176,6 +188,8 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
 #pragma unroll 1
     for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
         load_tiles(k0 + BK);
+        // keep the prefetch ahead of the MFMA chain: its latency must be covered by the whole k-step
+        __builtin_amdgcn_sched_barrier(0);
         const float* Ac = As[cur];
         const float* Bc = Bs[cur];
 #pragma unroll
@@ -195,9 +209,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_gather(const float* __restric
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NSTAGE == 2) {
+            store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            store_tiles(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -245,7 +265,7 @@ struct WgradGeom {
 // lanes and published through LDS one stage ahead.  Blocks of one pixel split are mapped to one XCD
 // (block ids congruent mod 8) so the dy / x tiles they share are served from that XCD's L2.
 template <int TM, int TN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(kThreads) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ ws, WgradGeom g) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
