@@ -158,8 +158,9 @@ int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy,
  * (generator.py:157-158).  A channel-slice copy / add over M pixels covers both and their backward. */
 int snn_copy_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
 int snn_add_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
-/* dst = a + b (dense, n elements) */
-int snn_add(const float* a, const float* b, float* dst, int64_t n, void* stream);
+/* dst = a + b over M pixels x C channels, each operand with its own pixel stride */
+int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst, int64_t ldd,
+            int64_t M, int C, void* stream);
 int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream);
 int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n, void* stream);
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
     "snn_copy_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
     "snn_add_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
-    "snn_add": (c_int, [_P, _P, _P, _L, _P]),
+    "snn_add": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "snn_act_fwd": (c_int, [_I, _P, _P, _L, _P]),
     "snn_act_bwd": (c_int, [_I, _P, _P, _P, _P, _L, _P]),
     "snn_pool_fwd": (c_int, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -98,15 +98,19 @@ __global__ void k_channels(const float* __restrict__ src, int64_t lds, float* __
 }
 
 template <int VEC>
-__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int64_t n) {
-    const int64_t total = n / VEC;
+__global__ void k_add(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                      float* __restrict__ dst, int64_t ldd, int64_t M, int C) {
+    const int cv = C / VEC;
+    const int64_t total = M * cv;
     for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = e / cv;
+        const int c = (int)(e % cv) * VEC;
         if (VEC == 4) {
-            f32x4 x = reinterpret_cast<const f32x4*>(a)[e];
-            f32x4 y = reinterpret_cast<const f32x4*>(b)[e];
-            reinterpret_cast<f32x4*>(dst)[e] = x + y;
+            f32x4 x = *reinterpret_cast<const f32x4*>(a + m * lda + c);
+            f32x4 y = *reinterpret_cast<const f32x4*>(b + m * ldb + c);
+            *reinterpret_cast<f32x4*>(dst + m * ldd + c) = x + y;
         } else {
-            dst[e] = a[e] + b[e];
+            dst[m * ldd + c] = a[m * lda + c] + b[m * ldb + c];
         }
     }
 }
@@ -326,11 +330,15 @@ extern "C" int snn_add_channels(const float* src, int64_t lds, float* dst, int64
     return channels_op(true, src, lds, dst, ldd, M, C, stream);
 }
 
-extern "C" int snn_add(const float* a, const float* b, float* dst, int64_t n, void* stream) {
-    SNN_REQUIRE(a && b && dst && n > 0, "snn_add: bad arguments");
-    bool v4 = n % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(dst);
-    if (v4) hipLaunchKernelGGL(k_add<4>, dim3(grid_for(n / 4)), dim3(kThreads), 0, (hipStream_t)stream, a, b, dst, n);
-    else hipLaunchKernelGGL(k_add<1>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, a, b, dst, n);
+extern "C" int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst, int64_t ldd, int64_t M,
+                       int C, void* stream) {
+    SNN_REQUIRE(a && b && dst && M > 0 && C > 0 && lda >= C && ldb >= C && ldd >= C, "snn_add: bad arguments");
+    bool v4 = C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldd % 4 == 0 && aligned16(a) && aligned16(b) &&
+              aligned16(dst);
+    if (v4) hipLaunchKernelGGL(k_add<4>, dim3(grid_for(M * (C / 4))), dim3(kThreads), 0, (hipStream_t)stream, a, lda,
+                               b, ldb, dst, ldd, M, C);
+    else hipLaunchKernelGGL(k_add<1>, dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, a, lda, b, ldb,
+                            dst, ldd, M, C);
     SNN_CHECK_LAUNCH("snn_add");
     return 0;
 }

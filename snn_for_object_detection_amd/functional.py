@@ -46,8 +46,39 @@ def _require_device(t: torch.Tensor, what: str) -> None:
         raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
 
 
+def cl_stride(x: torch.Tensor) -> Optional[int]:
+    """Pixel stride ``ld`` when the logical ``[..., C, H, W]`` tensor is stored frame-contiguously as
+    ``[..., H, W, ld >= C]`` with channel stride 1 (dense channels-last, or a channel slice of a wider
+    channels-last buffer); ``None`` otherwise."""
+    if x.dim() < 3:
+        return None
+    *lead, C, H, W = x.shape
+    st = x.stride()
+    sc, sh, sw = st[-3], st[-2], st[-1]
+    if C > 1 and sc != 1:
+        return None
+    if W > 1:
+        ld = sw
+    elif H > 1:
+        ld = sh
+    else:
+        ld = C
+        for d in range(len(lead) - 1, -1, -1):
+            if lead[d] > 1:
+                ld = st[d]
+                break
+    if ld < C or (W > 1 and sw != ld) or (H > 1 and sh != W * ld):
+        return None
+    expect = H * W * ld
+    for d in range(len(lead) - 1, -1, -1):
+        if lead[d] > 1 and st[d] != expect:
+            return None
+        expect *= lead[d]
+    return ld
+
+
 def is_channels_last(x: torch.Tensor) -> bool:
-    """True when the logical ``[..., C, H, W]`` tensor is stored densely as ``[..., H, W, C]``."""
+    """True when the logical ``[..., C, H, W]`` tensor is stored DENSELY as ``[..., H, W, C]``."""
     nd = x.dim()
     perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
     return x.permute(perm).is_contiguous()
@@ -63,9 +94,64 @@ def _new_cl(lead: Sequence[int], C: int, H: int, W: int, like: torch.Tensor) -> 
     return _cl_view(torch.empty((*lead, H, W, C), device=like.device, dtype=_F32))
 
 
+def _alias(root: torch.Tensor, storage_offset: int, T: int, B: int, C: int, H: int, W: int, ld: int) -> torch.Tensor:
+    """A fresh tensor (no autograd view relation) over ``root``'s storage: logical ``[T,B,C,H,W]``,
+    channels-last with pixel stride ``ld``.  Only the HIP kernels write through such aliases."""
+    t = torch.empty(0, device=root.device, dtype=_F32)
+    t.set_(root.untyped_storage(), storage_offset, (T, B, C, H, W), (B * H * W * ld, H * W * ld, 1, W * ld, ld))
+    return t
+
+
+class ConcatPromise:
+    """A lazily allocated channels-last buffer ``[T,B,H,W,total_c]`` that several producers fill slice by
+    slice (the Dense merge of generator.py:157-161 without the copy).  A promise nested in a parent
+    destination is itself a channel slice of the parent's buffer."""
+
+    def __init__(self, total_c: int, parent: "Optional[Dest]" = None):
+        self.total_c, self.parent = total_c, parent
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, T: int, B: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+        if self.buf is None:
+            if self.parent is not None:
+                self.buf = self.parent.tensor(T, B, self.total_c, H, W, like)
+            else:
+                self.buf = _new_cl((T, B), self.total_c, H, W, like)
+        if tuple(self.buf.shape) != (T, B, self.total_c, H, W):
+            raise RuntimeError(f"Dense merge: branch outputs differ in shape: {tuple(self.buf.shape)} vs "
+                               f"{(T, B, self.total_c, H, W)}")
+        return self.buf
+
+
+class Dest:
+    """Where an operator must put its ``[T,B,c,H,W]`` result: channels ``off .. off+c`` of a promise."""
+
+    def __init__(self, promise: ConcatPromise, off: int, c: int):
+        self.promise, self.off, self.c = promise, off, c
+
+    def tensor(self, T: int, B: int, C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+        if C != self.c:
+            raise RuntimeError(f"destination slice holds {self.c} channels, operator produces {C}")
+        buf = self.promise.get(T, B, H, W, like)
+        return _alias(buf, buf.storage_offset() + self.off, T, B, C, H, W, cl_stride(buf))
+
+    def holds(self, x: torch.Tensor) -> bool:
+        """True when ``x`` already IS this destination (same storage, offset and pixel stride)."""
+        buf = self.promise.buf
+        if buf is None or x.dim() != 5 or x.shape[2] != self.c:
+            return False
+        return (x.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()
+                and x.storage_offset() == buf.storage_offset() + self.off and cl_stride(x) == cl_stride(buf)
+                and tuple(x.shape[:2]) == tuple(buf.shape[:2]) and tuple(x.shape[3:]) == tuple(buf.shape[3:]))
+
+
+def _out_tensor(dest: Optional[Dest], T: int, B: int, C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+    return dest.tensor(T, B, C, H, W, like) if dest is not None else _new_cl((T, B), C, H, W, like)
+
+
 def _raw_to_cl(x: torch.Tensor) -> torch.Tensor:
-    """Non-differentiable layout change to channels-last memory (same logical shape)."""
-    if is_channels_last(x):
+    """Non-differentiable layout change to (possibly channel-sliced) channels-last memory."""
+    if cl_stride(x) is not None:
         return x
     _require_device(x, "layout")
     xc = x.contiguous()
@@ -78,10 +164,24 @@ def _raw_to_cl(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _raw_dense_cl(x: torch.Tensor) -> torch.Tensor:
+    """Dense channels-last copy of a channel-sliced tensor (operators without a pixel-stride argument)."""
+    x = _raw_to_cl(x)
+    if is_channels_last(x):
+        return x
+    lead, (C, H, W) = x.shape[:-3], x.shape[-3:]
+    n = 1
+    for d in lead:
+        n *= d
+    out = _new_cl(lead, C, H, W, x)
+    _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr(), C, n * H * W, C, _stream())
+    return out
+
+
 def _raw_to_nchw(x: torch.Tensor) -> torch.Tensor:
     if x.is_contiguous():
         return x
-    x = _raw_to_cl(x)
+    x = _raw_dense_cl(x)
     lead, (C, H, W) = x.shape[:-3], x.shape[-3:]
     n = 1
     for d in lead:
@@ -103,7 +203,7 @@ class _ToChannelsLast(Function):
 
 def to_channels_last(x: torch.Tensor) -> torch.Tensor:
     """Differentiable entry adapter for callers holding NCHW-contiguous frames (soda.py:138-144)."""
-    if is_channels_last(x):
+    if cl_stride(x) is not None:
         return x
     return _ToChannelsLast.apply(x)
 
@@ -154,7 +254,7 @@ class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int, slot=None):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None):
         _require_device(x, "conv2d input")
         _require_device(weight, "conv2d weight")
         T, B, Cin, H, W = _dims5(x)
@@ -165,10 +265,10 @@ class _Conv2d(Function):
         Wo = (W + 2 * pad - KW) // stride + 1
         x = _raw_to_cl(x)
         w = weight.detach()
-        w_ohwi = w if is_channels_last(w) else _raw_to_cl(w)
-        y = _new_cl((T, B), Cout, Ho, Wo, x)
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w_ohwi.data_ptr(), y.data_ptr(), Cout, T * B, H, W, Cin,
-                  Ho, Wo, Cout, KH, KW, stride, pad, 0, _stream())
+        w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
+        y = _out_tensor(dest, T, B, Cout, Ho, Wo, x)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
+                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, _stream())
         ctx.save_for_backward(x, w_ohwi)
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
         ctx.slot = slot
@@ -179,31 +279,33 @@ class _Conv2d(Function):
         x, w_ohwi = ctx.saved_tensors
         T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = ctx.geom
         gy = _raw_to_cl(gy)
+        ldg, ldx = cl_stride(gy), cl_stride(x)
         st = _stream()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
             _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
             dx = _new_cl((T, B), Cin, H, W, x)
-            _hip.call("snn_conv2d_dgrad", gy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
+            _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
                       Ho, Wo, Cout, KH, KW, stride, pad, 0, st)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
             ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
             if ctx.slot is not None:
-                _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, ctx.slot.buf.data_ptr(), T * B,
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(), T * B,
                           H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, st)
             else:
                 dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
-                _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, gy.data_ptr(), Cout, dw_ohwi.data_ptr(), T * B, H,
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
                           W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
+           dest: Optional[Dest] = None) -> torch.Tensor:
     seq, single = as_sequence(x)
-    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight))
+    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest)
     return y[0] if single else y
 
 
@@ -226,9 +328,10 @@ class _AffineNeuron(Function):
 
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, cfg):
-        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot) = cfg
+        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest) = cfg
         _require_device(y, "norm/neuron input")
         y = _raw_to_cl(y)
+        ldy = cl_stride(y)
         T, B, C, H, W = _dims5(y)
         M = B * H * W
         st = _stream()
@@ -251,11 +354,11 @@ class _AffineNeuron(Function):
             else:
                 n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
                 partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
-                _hip.call("snn_bn_stats", y.data_ptr(), C, T, M, C, partial.data_ptr(), st)
+                _hip.call("snn_bn_stats", y.data_ptr(), ldy, T, M, C, partial.data_ptr(), st)
                 _hip.call("snn_bn_stats_finalize", partial.data_ptr(), T, M, C, g_ptr, b_ptr, eps, momentum,
                           _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
                           alpha.data_ptr(), beta.data_ptr(), st)
-        out = _new_cl((T, B), C, H, W, y)
+        out = _out_tensor(dest, T, B, C, H, W, y)
         has_state = neuron != _hip.NEURON_NONE
         vT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
         iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
@@ -267,13 +370,15 @@ class _AffineNeuron(Function):
             v0 = _expand_state(v0, (B, C, H, W), dev)
         if i0 is not None:
             i0 = _expand_state(i0, (B, C, H, W), dev)
-        _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), C, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
-                  out.data_ptr(), C, _ptr(vT) if has_state else None, _ptr(iT) if has_state else None, _ptr(vdec),
-                  T, M, C, params, st)
+        _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
+                  out.data_ptr(), cl_stride(out), _ptr(vT) if has_state else None, _ptr(iT) if has_state else None,
+                  _ptr(vdec), T, M, C, params, st)
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
         ctx.has_v0 = v0 is not None
         ctx.has_i0 = i0 is not None
+        if neuron == _hip.NEURON_LI_TANH and need_grad and not is_channels_last(out):
+            raise RuntimeError("LI+Tanh output placed in a concat slice is not supported for training")
         state = vdec if neuron == _hip.NEURON_LIF else (out if neuron == _hip.NEURON_LI_TANH else None)
         ctx.save_for_backward(y, gamma, mean, invstd, alpha, state)
         if not has_state:
@@ -293,12 +398,13 @@ class _AffineNeuron(Function):
             g_out = torch.zeros((T, B, H, W, C), device=dev, dtype=_F32)
             g_out = _cl_view(g_out)
         g_out = _raw_to_cl(g_out)
+        ldg, ldy = cl_stride(g_out), cl_stride(y)
         if not has_state:
             g_vT = g_iT = None
         if g_vT is not None:
-            g_vT = _raw_to_cl(g_vT)
+            g_vT = _raw_dense_cl(g_vT)
         if g_iT is not None:
-            g_iT = _raw_to_cl(g_iT)
+            g_iT = _raw_dense_cl(g_iT)
         need_y = ctx.needs_input_grad[0]
         need_gamma = has_bn and gamma is not None and ctx.needs_input_grad[1]
         need_bias = has_bn and ctx.needs_input_grad[2]
@@ -312,7 +418,7 @@ class _AffineNeuron(Function):
             sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
         # eval-mode BN has no batch coupling: dy = alpha * gx, applied while gx is written
         scale = alpha if (has_bn and use_running) else None
-        _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), C, _ptr(state), y.data_ptr(), C, _ptr(g_vT),
+        _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy, _ptr(g_vT),
                   _ptr(g_iT), _ptr(scale), gx.data_ptr(), _ptr(g_v0), _ptr(g_i0), _ptr(sums), T, M, C, params, st)
         dy = dgamma = dbias = None
         if need_sums:
@@ -337,8 +443,8 @@ class _AffineNeuron(Function):
                           _ptr(dgamma), _ptr(dbias), 0, st)
             if need_y and not use_running:
                 # in place: dy overwrites gx
-                _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), C, coef[0].data_ptr(), coef[1].data_ptr(),
-                          coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
+                _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), ldy, coef[0].data_ptr(),
+                          coef[1].data_ptr(), coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
         if need_y:
             dy = _cl_view(gx)
         return dy, dgamma, dbias, g_v0, g_i0, None
@@ -349,11 +455,11 @@ def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
     s = s.detach()
     if s.dim() == 0 or tuple(s.shape) != tuple(shape):
         s = s.to(device=dev, dtype=_F32).expand(shape)
-    return _raw_to_cl(s)
+    return _raw_dense_cl(s)
 
 
 def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = None, bn=None,
-                  params: Optional[NeuronParams] = None):
+                  params: Optional[NeuronParams] = None, dest: Optional[Dest] = None):
     """Fused ``[Norm] -> [neuron]`` over a sequence or a single step.
 
     ``bn`` is an ``nn.BatchNorm2d``-like module (weight, bias, running stats, eps, momentum, training)
@@ -377,7 +483,8 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     v0 = i0 = None
     if state is not None:
         v0, i0 = state
-    cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias))
+    cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
+           dest)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
     new_state = NeuronState(vT, iT) if neuron != _hip.NEURON_NONE else None
     return (out[0] if single else out), new_state
@@ -385,40 +492,53 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
 
 # ------------------------------------------------------------------------------------------- merges
 class _Concat(Function):
-    """Dense merge: torch.cat(out, dim=1) per timestep (generator.py:157-158)."""
+    """Dense merge: torch.cat(out, dim=1) per timestep (generator.py:157-158), copying form."""
 
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, dest, *xs):
         xs = [_raw_to_cl(x) for x in xs]
         T, B, _, H, W = _dims5(xs[0])
         widths = [x.shape[2] for x in xs]
         Ct = sum(widths)
-        out = _new_cl((T, B), Ct, H, W, xs[0])
+        out = _out_tensor(dest, T, B, Ct, H, W, xs[0])
+        ldo = cl_stride(out)
         M, st, off = T * B * H * W, _stream(), 0
         for x, c in zip(xs, widths):
             _require_device(x, "concat input")
             if x.shape[0] != T or x.shape[1] != B or x.shape[3] != H or x.shape[4] != W:
                 raise RuntimeError("Dense merge: branch outputs differ in shape")
-            _hip.call("snn_copy_channels", x.data_ptr(), c, out.data_ptr() + 4 * off, Ct, M, c, st)
+            _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr() + 4 * off, ldo, M, c, st)
             off += c
         ctx.widths = widths
-        ctx.shape = (T, B, H, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = _raw_to_cl(g)
-        T, B, H, W = ctx.shape
-        Ct = sum(ctx.widths)
-        M, st, off = T * B * H * W, _stream(), 0
-        grads = []
+        grads, off = [None], 0
         for k, c in enumerate(ctx.widths):
-            if ctx.needs_input_grad[k]:
-                gk = _new_cl((T, B), c, H, W, g)
-                _hip.call("snn_copy_channels", g.data_ptr() + 4 * off, Ct, gk.data_ptr(), c, M, c, st)
-                grads.append(gk)
-            else:
-                grads.append(None)
+            grads.append(g.narrow(2, off, c) if ctx.needs_input_grad[k + 1] else None)  # channel-slice views
+            off += c
+        return tuple(grads)
+
+
+class _ConcatAssemble(Function):
+    """Dense merge without a copy: every branch output already IS its channel slice of ``whole``
+    (``ConcatPromise``); this node only ties the autograd graph together.  Backward hands each branch
+    the matching channel-slice VIEW of the incoming gradient (the kernels take a pixel stride)."""
+
+    @staticmethod
+    def forward(ctx, whole, *xs):
+        ctx.widths = [x.shape[2] for x in xs]
+        T, B, C, H, W = _dims5(whole)
+        return _alias(whole, whole.storage_offset(), T, B, C, H, W, cl_stride(whole))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _raw_to_cl(g)
+        grads, off = [None], 0
+        for k, c in enumerate(ctx.widths):
+            grads.append(g.narrow(2, off, c) if ctx.needs_input_grad[k + 1] else None)
             off += c
         return tuple(grads)
 
@@ -427,38 +547,68 @@ class _Sum(Function):
     """Residual merge: torch.stack(out).sum(0) (generator.py:145-146)."""
 
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, dest, *xs):
         xs = [_raw_to_cl(x) for x in xs]
         for x in xs:
             _require_device(x, "residual input")
             if x.shape != xs[0].shape:
                 raise RuntimeError("Residual merge: branch outputs differ in shape")
         T, B, C, H, W = _dims5(xs[0])
-        out = _new_cl((T, B), C, H, W, xs[0])
-        n, st = xs[0].numel(), _stream()
-        _hip.call("snn_add", xs[0].data_ptr(), xs[1].data_ptr(), out.data_ptr(), n, st)
+        out = _out_tensor(dest, T, B, C, H, W, xs[0])
+        ldo, M, st = cl_stride(out), T * B * H * W, _stream()
+        _hip.call("snn_add", xs[0].data_ptr(), cl_stride(xs[0]), xs[1].data_ptr(), cl_stride(xs[1]), out.data_ptr(),
+                  ldo, M, C, st)
         for x in xs[2:]:
-            _hip.call("snn_add", out.data_ptr(), x.data_ptr(), out.data_ptr(), n, st)
+            _hip.call("snn_add", out.data_ptr(), ldo, x.data_ptr(), cl_stride(x), out.data_ptr(), ldo, M, C, st)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return tuple(g if need else None for need in ctx.needs_input_grad)
+        return (None,) + tuple(g if need else None for need in ctx.needs_input_grad[1:])
 
 
-def concat_channels(xs: List[torch.Tensor]) -> torch.Tensor:
-    if len(xs) == 1:
+class _Place(Function):
+    """Copy a tensor into a destination slice (fallback when a producer could not write there itself)."""
+
+    @staticmethod
+    def forward(ctx, x, dest):
+        x = _raw_to_cl(x)
+        T, B, C, H, W = _dims5(x)
+        out = dest.tensor(T, B, C, H, W, x)
+        _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr(), cl_stride(out), T * B * H * W, C,
+                  _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def place(x: torch.Tensor, dest: Dest) -> torch.Tensor:
+    """``x`` as the channel slice ``dest`` of a concat buffer (no-op when it already lives there)."""
+    if dest.holds(x):
+        return x
+    return _Place.apply(x, dest)
+
+
+def concat_channels(xs: List[torch.Tensor], dest: Optional[Dest] = None) -> torch.Tensor:
+    if len(xs) == 1 and dest is None:
         return xs[0]
     seqs = [as_sequence(x) for x in xs]
-    out = _Concat.apply(*[s for s, _ in seqs])
+    out = _Concat.apply(dest, *[s for s, _ in seqs])
     return out[0] if seqs[0][1] else out
 
 
-def sum_tensors(xs: List[torch.Tensor]) -> torch.Tensor:
+def assemble_channels(promise: ConcatPromise, xs: List[torch.Tensor]) -> torch.Tensor:
+    """Zero-copy Dense merge of branch outputs that were produced inside ``promise``'s buffer."""
+    return _ConcatAssemble.apply(promise.buf, *xs)
+
+
+def sum_tensors(xs: List[torch.Tensor], dest: Optional[Dest] = None) -> torch.Tensor:
     if len(xs) == 1:
-        return xs[0]
+        return xs[0] if dest is None else place(as_sequence(xs[0])[0], dest)
     seqs = [as_sequence(x) for x in xs]
-    out = _Sum.apply(*[s for s, _ in seqs])
+    out = _Sum.apply(dest, *[s for s, _ in seqs])
     return out[0] if seqs[0][1] else out
 
 
@@ -467,7 +617,7 @@ class _Act(Function):
     @staticmethod
     def forward(ctx, x, act: int):
         _require_device(x, "activation input")
-        x = _raw_to_cl(x)
+        x = _raw_dense_cl(x)
         y = _cl_view(torch.empty(x.permute(0, 1, 3, 4, 2).shape, device=x.device, dtype=_F32))
         _hip.call("snn_act_fwd", act, x.data_ptr(), y.data_ptr(), x.numel(), _stream())
         ctx.act = act
@@ -477,7 +627,7 @@ class _Act(Function):
     @staticmethod
     def backward(ctx, gy):
         x, y = ctx.saved_tensors
-        gy = _raw_to_cl(gy)
+        gy = _raw_dense_cl(gy)
         gx = _cl_view(torch.empty(x.permute(0, 1, 3, 4, 2).shape, device=x.device, dtype=_F32))
         _hip.call("snn_act_bwd", ctx.act, x.data_ptr(), y.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(),
                   _stream())
@@ -494,7 +644,7 @@ class _Pool(Function):
     @staticmethod
     def forward(ctx, x, kind: int, k: int, stride: int):
         _require_device(x, "pool input")
-        x = _raw_to_cl(x)
+        x = _raw_dense_cl(x)
         T, B, C, H, W = _dims5(x)
         Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
         if Ho <= 0 or Wo <= 0:
@@ -509,7 +659,7 @@ class _Pool(Function):
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         kind, k, stride, T, B, C, H, W, Ho, Wo = ctx.geom
-        gy = _raw_to_cl(gy)
+        gy = _raw_dense_cl(gy)
         gx = _new_cl((T, B), C, H, W, x)
         _hip.call("snn_pool_bwd", kind, x.data_ptr(), gy.data_ptr(), gx.data_ptr(), T * B, H, W, C, Ho, Wo, k, stride,
                   _stream())
@@ -526,7 +676,7 @@ class _Upsample(Function):
     @staticmethod
     def forward(ctx, x, scale: int):
         _require_device(x, "upsample input")
-        x = _raw_to_cl(x)
+        x = _raw_dense_cl(x)
         T, B, C, H, W = _dims5(x)
         y = _new_cl((T, B), C, H * scale, W * scale, x)
         _hip.call("snn_upsample_fwd", x.data_ptr(), y.data_ptr(), T * B, H, W, C, scale, _stream())
@@ -536,7 +686,7 @@ class _Upsample(Function):
     @staticmethod
     def backward(ctx, gy):
         scale, T, B, C, H, W = ctx.geom
-        gy = _raw_to_cl(gy)
+        gy = _raw_dense_cl(gy)
         gx = _new_cl((T, B), C, H, W, gy)
         _hip.call("snn_upsample_bwd", gy.data_ptr(), gx.data_ptr(), T * B, H, W, C, scale, _stream())
         return gx, None

@@ -25,8 +25,8 @@ from . import _hip
 from . import functional as HF
 from .anchors import AnchorGenerator
 from .layer_gen import *  # noqa: F401,F403  (the reference re-exports the layer generators here)
-from .layer_gen import (Dense, HipBatchNorm2d, HipTanh, LayerGen, LICell, LIFCell, Residual, Return, StateStorage,
-                        Storage)
+from .layer_gen import (Dense, HipBatchNorm2d, HipConv2d, HipTanh, LayerGen, LICell, LIFCell, Residual, Return,
+                        StateStorage, Storage)
 
 ListGen = List[Union[LayerGen, "ListGen"]]
 ListState = List[Union[torch.Tensor, None, "ListState"]]
@@ -54,6 +54,7 @@ class BlockGen(nn.Module):
 
     def __init__(self, in_channels: int, cfgs: ListGen):
         super().__init__()
+        self.in_channels = in_channels
         self.out_channels = 0
         if isinstance(cfgs, Residual):
             self.merge = "residual"
@@ -65,14 +66,26 @@ class BlockGen(nn.Module):
 
         branch_list: List[nn.ModuleList] = []
         self.branch_state: List[List[bool]] = []
+        self._branch_channels: List[int] = []
         for branch_cfg in cfgs:
             layers, flags, channels = self._make_branch(in_channels, branch_cfg)
             branch_list.append(layers)
             self.branch_state.append(flags)
+            self._branch_channels.append(channels)
             self._account_channels(channels)
         self.net = nn.ModuleList(branch_list)
         # fused execution plan per branch: list of (kind, first_index, n_layers)
         self._plan = [self._plan_branch(branch) for branch in self.net]
+        # zero-copy Dense merge: channel offset of every branch inside the concat buffer, and the offset of
+        # the first branch that is a bare Pass (its content = the block input, which the PRODUCER of that
+        # input can write there directly when this block is the next layer of the parent branch)
+        self._offsets = [sum(self._branch_channels[:k]) for k in range(len(self._branch_channels))]
+        self._pass_offset: Optional[int] = None
+        if self.merge == "dense":
+            for k, branch in enumerate(self.net):
+                if len(branch) == 1 and isinstance(branch[0], nn.Identity):
+                    self._pass_offset = self._offsets[k]
+                    break
 
     # ------------------------------------------------------------------ construction
     def _make_branch(self, in_channels: int, cfg: ListGen) -> Tuple[nn.ModuleList, List[bool], int]:
@@ -122,15 +135,44 @@ class BlockGen(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ execution
-    def forward(self, X: torch.Tensor, state: Optional[ListState] = None) -> Tuple[torch.Tensor, ListState]:
-        """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence)."""
+    def forward(self, X: torch.Tensor, state: Optional[ListState] = None, dest=None, promise=None):
+        """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence).
+
+        ``dest`` / ``promise`` are internal (``functional.Dest`` / ``ConcatPromise``): on sequences the
+        Dense merge is zero-copy - each branch's last operator writes its channel slice of one shared
+        buffer, nested blocks write slices of their parent's slice, and a bare ``Pass`` branch costs nothing
+        when the layer that produced the block input was told to write it there (look-ahead below).
+        """
         out = []
         out_state = []
         state = [None] * len(self.net) if state is None else state
-        for branch, flags, plan, branch_state in zip(self.net, self.branch_state, self._plan, state):
+        zero_copy = X.dim() == 5
+        if not zero_copy:
+            dest = promise = None
+        if self.merge == "dense" and zero_copy and promise is None:
+            promise = HF.ConcatPromise(self.out_channels, parent=dest)
+        for b, (branch, flags, plan, branch_state) in enumerate(zip(self.net, self.branch_state, self._plan, state)):
             branch_state = [None] * len(branch) if branch_state is None else branch_state
+            if self.merge == "dense":
+                branch_dest = HF.Dest(promise, self._offsets[b], self._branch_channels[b]) if zero_copy else None
+            elif self.merge == "forward":
+                branch_dest = dest
+            else:
+                branch_dest = None  # residual: branches are summed, only the sum is placed
             Y = X
-            for kind, idx, span in plan:
+            pending = None  # promise prepared for the next step (a Dense block with a Pass branch)
+            for k, (kind, idx, span) in enumerate(plan):
+                last = k == len(plan) - 1
+                step_dest = branch_dest if last else None
+                step_promise, pending = pending, None
+                if zero_copy and not last:
+                    nkind, nidx, _ = plan[k + 1]
+                    nxt = branch[nidx]
+                    if nkind == "layer" and isinstance(nxt, BlockGen) and nxt._pass_offset is not None:
+                        parent = branch_dest if (k + 1 == len(plan) - 1) else None
+                        pending = HF.ConcatPromise(nxt.out_channels, parent=parent)
+                        step_dest = HF.Dest(pending, nxt._pass_offset, nxt.in_channels)
+                layer = branch[idx]
                 if kind == "norm_neuron":
                     holder = branch[idx + 1]
                     cell = _neuron_cell(holder)
@@ -138,20 +180,32 @@ class BlockGen(nn.Module):
                     if span == 3:
                         neuron = _hip.NEURON_LI_TANH
                     old = branch_state[idx + 1]
-                    Y, new = HF.affine_neuron(Y, neuron, old, bn=branch[idx], params=cell.params)
+                    # LI+Tanh keeps its own output for the backward pass and wants it dense: place by copy
+                    direct = step_dest if neuron != _hip.NEURON_LI_TANH else None
+                    Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct)
                     if isinstance(holder, StateStorage):
                         holder.record(old, Y, new)
                     branch_state[idx + 1] = new
+                elif isinstance(layer, BlockGen):
+                    Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise)
+                elif isinstance(layer, HipConv2d):
+                    Y = layer(Y, dest=step_dest)
+                elif isinstance(layer, (LIFCell, LICell)):
+                    Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest)
                 elif flags[idx]:
-                    Y, branch_state[idx] = branch[idx](Y, branch_state[idx])
+                    Y, branch_state[idx] = layer(Y, branch_state[idx])
                 else:
-                    Y = branch[idx](Y)
+                    Y = layer(Y)
+                if step_dest is not None:
+                    Y = HF.place(Y, step_dest)  # no-op when the operator wrote there itself
+            if branch_dest is not None and not plan:
+                Y = HF.place(Y, branch_dest)
             out.append(Y)
             out_state.append(branch_state)
         if self.merge == "residual":
-            merged = HF.sum_tensors(out)
+            merged = HF.sum_tensors(out, dest=dest)
         elif self.merge == "dense":
-            merged = HF.concat_channels(out)
+            merged = HF.assemble_channels(promise, out) if zero_copy else HF.concat_channels(out)
         else:
             merged = out[0]
         return merged, out_state

@@ -67,7 +67,7 @@ def work_of(name: str, a):
         M, C = a[4], a[5]
         return "k_channels", 0.0, (8.0 if name == "snn_copy_channels" else 12.0) * M * C
     if name == "snn_add":
-        return "k_add", float(a[3]), 12.0 * a[3]
+        return "k_add", float(a[6]) * a[7], 12.0 * a[6] * a[7]
     if name in ("snn_nchw_to_nhwc", "snn_nhwc_to_nchw"):
         n = float(a[2]) * a[3] * a[4] * a[5]
         return "k_layout", 0.0, 8.0 * n
