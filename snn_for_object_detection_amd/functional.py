@@ -567,6 +567,47 @@ class _Sum(Function):
         return (None,) + tuple(g if need else None for need in ctx.needs_input_grad[1:])
 
 
+class _Fanout(Function):
+    """One tensor consumed by ``n`` branches of a block (generator.py:181-187 hands every branch the same X).
+
+    Forward returns ``n`` aliases (no copy); backward adds the branch gradients with the strided add
+    kernel, so gradient accumulation stays on this library's kernels and accepts channel-sliced grads."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        outs = []
+        for _ in range(n):
+            t = torch.empty(0, device=x.device, dtype=x.dtype)
+            t.set_(x.untyped_storage(), x.storage_offset(), x.size(), x.stride())
+            outs.append(t)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        single = gs[0].dim() == 4
+        seqs = [_raw_to_cl(g.unsqueeze(0) if single else g) for g in gs]
+        T, B, C, H, W = _dims5(seqs[0])
+        out = _new_cl((T, B), C, H, W, seqs[0])
+        M, st = T * B * H * W, _stream()
+        _hip.call("snn_add", seqs[0].data_ptr(), cl_stride(seqs[0]), seqs[1].data_ptr(), cl_stride(seqs[1]),
+                  out.data_ptr(), C, M, C, st)
+        for g in seqs[2:]:
+            _hip.call("snn_add", out.data_ptr(), C, g.data_ptr(), cl_stride(g), out.data_ptr(), C, M, C, st)
+        return (out[0] if single else out), None
+
+
+def fanout(x: torch.Tensor, n: int):
+    """``n`` aliases of ``x`` for the ``n`` branches of a block; their gradients are summed by a HIP kernel."""
+    if n == 1 or not x.requires_grad:
+        return [x] * n
+    return list(_Fanout.apply(x, n))
+
+
 class _Place(Function):
     """Copy a tensor into a destination slice (fallback when a producer could not write there itself)."""
 

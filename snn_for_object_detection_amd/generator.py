@@ -151,6 +151,7 @@ class BlockGen(nn.Module):
             dest = promise = None
         if self.merge == "dense" and zero_copy and promise is None:
             promise = HF.ConcatPromise(self.out_channels, parent=dest)
+        inputs = HF.fanout(X, len(self.net))
         for b, (branch, flags, plan, branch_state) in enumerate(zip(self.net, self.branch_state, self._plan, state)):
             branch_state = [None] * len(branch) if branch_state is None else branch_state
             if self.merge == "dense":
@@ -159,7 +160,7 @@ class BlockGen(nn.Module):
                 branch_dest = dest
             else:
                 branch_dest = None  # residual: branches are summed, only the sum is placed
-            Y = X
+            Y = inputs[b]
             pending = None  # promise prepared for the next step (a Dense block with a Pass branch)
             for k, (kind, idx, span) in enumerate(plan):
                 last = k == len(plan) - 1
