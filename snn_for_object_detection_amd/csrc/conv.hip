@@ -48,7 +48,12 @@ struct ConvGeom {
     // taps kh = kh0 + stride*jh (jh < nkh), kw = kw0 + stride*jw (jw < nkw) reach them, with source pixel
     // iy = (hi + pad - kh0)/stride - jh (exact).  For stride 1 there is a single class with every tap.
     int ph, pw, kh0, kw0, nkh, nkw, OHc, OWc;
+    // ceil(2^32 / d) for d = IC and d = (DGRAD ? nkw : KW): q = umulhi(n, magic) == n / d for n * d < 2^32
+    unsigned magic_ic, magic_kw;
 };
+
+static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
 
 template <int BN, int WM, int WN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     // ---- per-thread loader geometry: rows lr + 32*j, k offset kq
     const int lr = tid >> 3, kq = (tid & 7) * 4;
     int a_y0[4], a_x0[4];
-    int64_t a_base[4];
+    int a_base[4];  // first pixel of the image (the host checks img * IH * IW < 2^31)
     bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
         int64_t t = mm / ow_;
         int oy = (int)(t % oh_);
         int64_t img = t / oh_;
-        a_base[j] = img * g.IH * (int64_t)g.IW;
+        a_base[j] = (int)(img * g.IH * (int64_t)g.IW);
         if (!DGRAD) {
             a_y0[j] = oy * g.stride - g.pad;
             a_x0[j] = ox * g.stride - g.pad;
@@ -97,15 +102,15 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 
     // k index -> (source pixel offset, weight column)
     auto decode_k = [&](int kk, int& dy, int& dx, int& c, int& wcol) {
-        int tap = kk / g.IC;
+        int tap = div_magic(kk, g.IC, g.magic_ic);
         c = kk - tap * g.IC;
         if (!DGRAD) {
-            int kh = tap / g.KW, kw = tap - kh * g.KW;
+            int kh = div_magic(tap, g.KW, g.magic_kw), kw = tap - kh * g.KW;
             dy = kh;
             dx = kw;
             wcol = kk;
         } else {
-            int jh = tap / g.nkw, jw = tap - jh * g.nkw;
+            int jh = div_magic(tap, g.nkw, g.magic_kw), jw = tap - jh * g.nkw;
             dy = -jh;
             dx = -jw;
             wcol = ((g.kh0 + g.stride * jh) * g.KW + (g.kw0 + g.stride * jw)) * g.IC + c;
@@ -116,6 +121,13 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 
     auto load_tiles = [&](int k0) {
         const int kk = k0 + kq;
+#ifdef SNN_ABL_NOLOAD
+        if (k0 > 0) {  // timing ablation only: keep the first tile, skip every later global load
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j][0] += 1.0f;
+            return;
+        }
+#endif
         if (VEC) {
             // Branch-free: every lane always loads from a clamped (valid) address and masks the value afterwards,
             // so the whole k-step stays one basic block and the scheduler can interleave these loads with MFMAs.
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
                 const int iy = a_y0[j] + dy, ix = a_x0[j] + dx;
                 const bool ok = kin & a_ok[j] & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
                 const int iyc = min(max(iy, 0), g.IH - 1), ixc = min(max(ix, 0), g.IW - 1);
-                f32x4 v = *reinterpret_cast<const f32x4*>(in + (a_base[j] + (int64_t)(iyc * g.IW + ixc)) * g.ldi + c);
+                f32x4 v = *reinterpret_cast<const f32x4*>(in + (int64_t)(a_base[j] + iyc * g.IW + ixc) * g.ldi + c);
                 ra[j] = ok ? v : zero;
             }
 #pragma unroll
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
                     const int iy = a_y0[j] + dy, ix = a_x0[j] + dx;
                     float v = 0.f;
                     if (kin && a_ok[j] && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
-                        v = in[(a_base[j] + (int64_t)iy * g.IW + ix) * g.ldi + c];
+                        v = in[(int64_t)(a_base[j] + iy * g.IW + ix) * g.ldi + c];
                     ra[j][e] = v;
                 }
 #pragma unroll
@@ -201,6 +213,12 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(&Bc[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
+#ifdef SNN_ABL_NOMFMA
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][0] += a[i][0] * b[j][0] + a[i][1] * b[j][1] + a[i][2] * b[j][2] + a[i][3] * b[j][3];
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -208,6 +226,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+#endif
         }
         if (NSTAGE == 2) {
             store_tiles(cur ^ 1);
@@ -496,6 +515,9 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     g.ldi = ldx; g.ldo = ldy;
     g.Ktot = g.KtotFull = KH * KW * Cin;
     g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
+    g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
+    SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
+                "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     return launch_gather<false>(x, w, y, g, accumulate, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
@@ -511,6 +533,8 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldi = lddy; g.ldo = lddx;
     g.KtotFull = KH * KW * Cout;
+    SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
+                "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     // one launch per stride phase: each class multiplies only the taps that can reach it
     for (int ph = 0; ph < stride && ph < H; ++ph)
         for (int pw = 0; pw < stride && pw < W; ++pw) {
@@ -522,6 +546,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.OWc = (W - pw + stride - 1) / stride;
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
+            g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
             int rc = launch_gather<true>(dy, wt, dx, g, accumulate, (hipStream_t)stream, "snn_conv2d_dgrad");
             if (rc) return rc;
         }

@@ -1,0 +1,84 @@
+"""BASELINE-size checks (TinyYolo GEN1 304x240, B=5, T=32) through size-independent properties - the CPU
+oracle cannot run these sizes in test time.
+
+* chunked == whole: running the sequence as two halves with the carried state (the reference's streaming
+  protocol) gives bit-identical spikes / predictions to one layer-major pass;
+* determinism: two identical steps give bit-identical loss and gradients;
+* conv linearity at the dominant full-size shapes; BatchNorm scale invariance of the fused Norm+LIF.
+"""
+import pytest
+import torch
+
+from tests.util import rel_err, synthetic_events, synthetic_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import snn_for_object_detection_amd as pkg
+    return pkg
+
+
+def test_fullsize_chunked_equals_whole_eval(S):
+    T, B, H, W = 32, 5, 240, 304
+    torch.manual_seed(2)
+    model = S.TinyYolo(num_classes=2, time_window=0).cuda().eval()   # eval: running stats, no cross-chunk BN coupling
+    X = synthetic_events(T, B, H, W, p=0.05).cuda()
+    with torch.no_grad():
+        (anchors, cls_w, box_w), st_w = model._forward_impl(X, None)
+        (_, _, _), st_h = model._forward_impl(X[: T // 2], None)
+        (_, cls_c, box_c), st_c = model._forward_impl(X[T // 2:], st_h)
+    assert anchors.shape == (13545, 4) and cls_w.shape == (B, 13545, 3) and box_w.shape == (B, 13545, 4)
+    assert torch.equal(cls_w, cls_c) and torch.equal(box_w, box_c)
+    # final LIF state of the first backbone layer identical too
+    assert torch.equal(st_w[0][0][2].v, st_c[0][0][2].v) and torch.equal(st_w[0][0][2].i, st_c[0][0][2].i)
+
+
+def test_fullsize_step_is_deterministic(S):
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 32, 5, 240, 304
+    X, labels = synthetic_events(T, B, H, W, p=0.05).cuda(), synthetic_labels(B).cuda()
+    results = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+        tr = FlatTrainer(model)
+        tr.zero_grad()
+        loss = model.training_step((X, labels))
+        loss.backward()
+        results.append((loss.detach().clone(), tr.flat_grad.clone()))
+        del model, tr
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+    g = results[0][1]
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,H,W", [(128, 128, 3, 1, 30, 38), (64, 128, 3, 2, 120, 152), (768, 256, 1, 1, 30, 38)])
+def test_fullsize_conv_linearity(S, Cin, Cout, k, s, H, W):
+    HF = S.functional
+    torch.manual_seed(Cin + k)
+    N = 160
+    x1 = torch.randn(N, 1, Cin, H, W, device="cuda")
+    x2 = torch.randn(N, 1, Cin, H, W, device="cuda")
+    w = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
+    y12 = HF.conv2d(2.0 * x1 + x2, w, s, k // 2)
+    y = 2.0 * HF.conv2d(x1, w, s, k // 2) + HF.conv2d(x2, w, s, k // 2)
+    assert rel_err(y12, y) < 1e-5
+
+
+def test_fullsize_norm_lif_scale_invariance(S):
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    HF = S.functional
+    torch.manual_seed(1)
+    y = torch.randn(32, 5, 64, 120, 152, device="cuda")
+    bn = HipBatchNorm2d(64).cuda().train()
+    z1, _ = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn)
+    z2, _ = HF.affine_neuron(4.0 * y, _hip.NEURON_LIF, None, bn=bn)   # batch-norm removes the scale (up to eps)
+    assert (z1 != z2).float().mean().item() < 1e-4
+    rate = z1.mean().item()
+    assert 0.0 < rate < 0.5
