@@ -554,11 +554,13 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
 }
 
 namespace {
-struct WgradTile { int bm, bn, id; };
+struct WgradTile { int bm, bn, id, blocks_per_cu; };
 // candidate block tiles (out-channels x (tap,ci) columns); pick the one that wastes the least MFMA work on
 // padding, larger tiles first on ties (fewer LDS / L2 bytes per FLOP)
 static WgradTile wgrad_tile(int Cout, int Ktot) {
-    static const WgradTile cand[] = {{128, 128, 0}, {64, 256, 1}, {32, 256, 2}, {128, 64, 3}, {64, 64, 4}, {32, 128, 5}};
+    // blocks_per_cu: residency of each variant (registers / LDS), used to size the pixel split to ONE full wave
+    static const WgradTile cand[] = {{128, 128, 0, 3}, {64, 256, 1, 3}, {32, 256, 2, 4},
+                                     {128, 64, 3, 3},  {64, 64, 4, 3},  {32, 128, 5, 3}};
     WgradTile best = cand[0];
     double best_eff = -1.0;
     for (const WgradTile& c : cand) {
@@ -579,12 +581,13 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     const int64_t Ktot = (int64_t)KH * KW * Cin;
     const WgradTile t = wgrad_tile(Cout, (int)Ktot);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
-    int64_t s = snn_ceil_div(3 * SNN_NUM_CU, tiles);                  // ~3 blocks per CU
+    // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time)
+    int64_t s = ((int64_t)t.blocks_per_cu * SNN_NUM_CU) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
     if (s > max_by_work) s = max_by_work;
     if (s > max_by_mem) s = max_by_mem;
-    if (s > 8) s = (s + 7) / 8 * 8;  // whole groups of 8 splits: one split per XCD at a time
+    if (s >= 32) s = s / 8 * 8;  // whole groups of 8 splits: one split per XCD at a time (XCD-aware mapping)
     if (s > 32768) s = 32768;
     if (s < 1) s = 1;
     return (int)s;
