@@ -168,12 +168,20 @@ def main():
         table = prof.summary()
         total_ms = sum(r["ms"] for r in table.values())
         name, row = max(table.items(), key=lambda kv: kv[1]["ms"])
+        # HBM bytes per launch of that kernel: rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 per the
+        # gfx950 correction, + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/ - bench.py cannot
+        # run the profiler on itself, so the field is null when no such file is present
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and (T, B, H, W) == (32, 5, GEN1_H, GEN1_W):
+            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS,
-            "unit": "TFLOP/s", "frac": row["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": row["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
             "avg_launch_us": row["avg_us"], "launches_per_step": row["calls"] // 2,
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],
+            "all_kernels_ms_per_step": total_ms / 2,
         }
         if args.kernel_table:
             for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
