@@ -33,14 +33,16 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 1
+#define SNN_ABI_VERSION 2
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
     SNN_NEURON_NONE = 0,   /* plain per-(t,c) affine (BatchNorm apply)            */
     SNN_NEURON_LIF = 1,    /* norse LIFCell step, layer_gen.py:232-235            */
     SNN_NEURON_LI = 2,     /* norse LICell step,  layer_gen.py:252-254            */
-    SNN_NEURON_LI_TANH = 3 /* LICell followed by nn.Tanh, tiny_yolo.py:39-44      */
+    SNN_NEURON_LI_TANH = 3,/* LICell followed by nn.Tanh, tiny_yolo.py:39-44      */
+    SNN_NEURON_SLI = 4,    /* saturable leaky integrator, sli.py:110-126          */
+    SNN_NEURON_SYNAPSE = 5 /* mediator-concentration synapse, synapse.py:73-103   */
 };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
@@ -57,6 +59,11 @@ typedef struct snn_neuron_params {
     float v_th;    /* 1 */
     float v_reset; /* 0 */
     float alpha;   /* SuperSpike slope, 100 */
+    float v_st;    /* SLI saturation potential, 1 (sli.py:38-39)                              */
+    float tau_sec; /* synapse: mediator secretion rate 1/1e-3 (synapse.py:26-27)              */
+    float tau_dis; /* synapse: mediator dissociation rate 1/5e-3 (synapse.py:29-30)           */
+    float dt;      /* synapse integration step 1e-3 (synapse.py:77)                           */
+    float sigma;   /* synapse inhibition, 0 = off (synapse.py:32-36)                          */
 } snn_neuron_params;
 
 int snn_abi_version(void);
@@ -119,8 +126,12 @@ int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C,
  *   LIF    : i' = i + x; vd = v + c_mem*((v_leak - v) + i'); i = i' + c_syn*i';
  *            z = (vd - v_th > 0); v = (1-z)*vd + z*v_reset; out[t] = z
  *   LI     : i' = i + x; v = v + c_mem*((v_leak - v) + i'); i = i' + c_syn*i'; out[t] = v (or tanh(v))
+ *   SLI    : as LI with the input gated: i' = i + x*sigmoid(v_st - |v|)
+ *   SYNAPSE: p = p + ((x - p)*(x > 0 ? tau_sec : tau_dis))*dt; g = sigma ? 4*sigma*(p - sigma*p^2) : p;
+ *            out[t] = max(g, 0); the state is p alone (held in the v slot, i unused)
  *   v0/i0 NULL -> initial state (v = v_leak, i = 0); vT/iT NULL -> final state not written.
- *   vdec (LIF, training) receives the pre-reset potential vd[t] for the surrogate backward.
+ *   vdec (training) receives what the backward scan needs per step: LIF the pre-reset potential vd[t],
+ *   SLI the potential BEFORE the step, SYNAPSE the new concentration p[t].
  * Layout: y/out/vdec are [T][M][C-slice] with pixel strides ldy/ldo (vdec dense, ld = C). */
 int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
                           const float* alpha, const float* beta,
@@ -133,12 +144,14 @@ int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
  * gradients of the final state; writes gx = dL/dx[t] (dense [T][M][C]), g_v0/g_i0 (may be NULL)
  * and, when `sums` != NULL, per-block partial sums of gx and gx*y per (t,c) for the BatchNorm
  * backward (`sums` scratch of snn_affine_neuron_bwd_sums_size() doubles, y must be given).
- * `state` is vdec for LIF, out (tanh output) for LI_TANH, unused otherwise.
- * scale (may be NULL): gx is multiplied by scale[t,c] before it is written (eval-mode BN: dy = alpha*gx). */
+ * `state` is the forward's vdec buffer for LIF / SLI / SYNAPSE, out (tanh output) for LI_TANH, unused otherwise.
+ * alpha/beta (may be NULL = identity): the forward's affine, needed to rebuild x[t] for SLI / SYNAPSE.
+ * apply_scale != 0: gx is multiplied by alpha[t,c] before it is written (eval-mode BN: dy = alpha*gx). */
 size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C);
 int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state,
                           const float* y, int64_t ldy, const float* g_vT, const float* g_iT,
-                          const float* scale, float* gx, float* g_v0, float* g_i0, double* sums,
+                          const float* alpha, const float* beta, int apply_scale,
+                          float* gx, float* g_v0, float* g_i0, double* sums,
                           int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
 
 /* BatchNorm backward, second phase.  From the partial sums: per-(t,c)
@@ -163,6 +176,13 @@ int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst
             int64_t M, int C, void* stream);
 int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream);
 int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n, void* stream);
+
+/* ConvLSTM cell (conv_lstm.py:51-78), pointwise part after the 1x1 gate convolution.  gates is dense
+ * [M][4C] = (input, forget, output, candidate); c_prev NULL = zero state.
+ *   c = sigmoid(f)*c_prev + sigmoid(i)*tanh(g);  h = sigmoid(o)*tanh(c) */
+int snn_lstm_cell_fwd(const float* gates, const float* c_prev, float* h, float* c, int64_t M, int C, void* stream);
+int snn_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c, const float* gh, const float* gc,
+                      float* g_gates, float* g_c_prev, int64_t M, int C, void* stream);
 
 /* Pool("A"/"M"/"S", k, stride) (layer_gen.py:146-173, common.py:18-49), no padding, floor mode. */
 int snn_pool_fwd(int kind, const float* x, float* y, int64_t N, int H, int W, int C,

@@ -12,15 +12,16 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnn_hip.so")
 
-NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH = 0, 1, 2, 3
+NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NeuronParams(Structure):
     _fields_ = [("c_mem", c_float), ("c_syn", c_float), ("v_leak", c_float), ("v_th", c_float),
-                ("v_reset", c_float), ("alpha", c_float)]
+                ("v_reset", c_float), ("alpha", c_float), ("v_st", c_float), ("tau_sec", c_float),
+                ("tau_dis", c_float), ("dt", c_float), ("sigma", c_float)]
 
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
@@ -42,7 +43,7 @@ SIGNATURES = {
     "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),
     "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),
-    "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I,
+    "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),
     "snn_bn_bwd_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     "snn_add": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "snn_act_fwd": (c_int, [_I, _P, _P, _L, _P]),
     "snn_act_bwd": (c_int, [_I, _P, _P, _P, _P, _L, _P]),
+    "snn_lstm_cell_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _P]),
+    "snn_lstm_cell_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "snn_pool_fwd": (c_int, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "snn_pool_bwd": (c_int, [_I, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "snn_upsample_fwd": (c_int, [_P, _P, _L, _I, _I, _I, _I, _P]),

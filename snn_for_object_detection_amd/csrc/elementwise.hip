@@ -143,6 +143,49 @@ __global__ void k_act_bwd(int act, const float* __restrict__ x, const float* __r
         gx[e] = gy[e] * act_g(act, x[e], y[e]);
 }
 
+// ------------------------------------------------------------------------------------------ ConvLSTM cell
+// gates[m][4C] = (input, forget, output, candidate) pre-activations, conv_lstm.py:66-76
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void k_lstm_fwd(const float* __restrict__ gates, const float* __restrict__ c_prev, float* __restrict__ h,
+                           float* __restrict__ c, int64_t M, int C) {
+    const int64_t total = M * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = e / C;
+        const int ch = (int)(e % C);
+        const float* g = gates + m * 4 * C;
+        const float I = sigmoidf_(g[ch]), F = sigmoidf_(g[C + ch]), O = sigmoidf_(g[2 * C + ch]);
+        const float G = tanhf(g[3 * C + ch]);
+        const float cp = c_prev ? c_prev[e] : 0.0f;
+        const float cn = F * cp + I * G;
+        c[e] = cn;
+        h[e] = O * tanhf(cn);
+    }
+}
+
+__global__ void k_lstm_bwd(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                           const float* __restrict__ c, const float* __restrict__ gh, const float* __restrict__ gc,
+                           float* __restrict__ g_gates, float* __restrict__ g_c_prev, int64_t M, int C) {
+    const int64_t total = M * C;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = e / C;
+        const int ch = (int)(e % C);
+        const float* g = gates + m * 4 * C;
+        const float I = sigmoidf_(g[ch]), F = sigmoidf_(g[C + ch]), O = sigmoidf_(g[2 * C + ch]);
+        const float G = tanhf(g[3 * C + ch]);
+        const float tc = tanhf(c[e]);
+        const float dh = gh ? gh[e] : 0.0f;
+        const float dc = (gc ? gc[e] : 0.0f) + dh * O * (1.0f - tc * tc);
+        const float cp = c_prev ? c_prev[e] : 0.0f;
+        float* d = g_gates + m * 4 * C;
+        d[ch] = (dc * G) * (I * (1.0f - I));
+        d[C + ch] = (dc * cp) * (F * (1.0f - F));
+        d[2 * C + ch] = (dh * tc) * (O * (1.0f - O));
+        d[3 * C + ch] = (dc * I) * (1.0f - G * G);
+        if (g_c_prev) g_c_prev[e] = dc * F;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ pooling
 __global__ void k_pool_fwd(int kind, const float* __restrict__ x, float* __restrict__ y, int64_t N, int H, int W, int C,
                            int Ho, int Wo, int k, int stride) {
@@ -354,6 +397,23 @@ extern "C" int snn_act_bwd(int act, const float* x, const float* y, const float*
     SNN_REQUIRE(x && y && gy && gx && n > 0 && act >= SNN_ACT_RELU && act <= SNN_ACT_TANH, "snn_act_bwd: bad arguments");
     hipLaunchKernelGGL(k_act_bwd, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, act, x, y, gy, gx, n);
     SNN_CHECK_LAUNCH("snn_act_bwd");
+    return 0;
+}
+
+extern "C" int snn_lstm_cell_fwd(const float* gates, const float* c_prev, float* h, float* c, int64_t M, int C,
+                                 void* stream) {
+    SNN_REQUIRE(gates && h && c && M > 0 && C > 0, "snn_lstm_cell_fwd: bad arguments");
+    hipLaunchKernelGGL(k_lstm_fwd, dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, gates, c_prev, h, c,
+                       M, C);
+    SNN_CHECK_LAUNCH("snn_lstm_cell_fwd");
+    return 0;
+}
+extern "C" int snn_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c, const float* gh,
+                                 const float* gc, float* g_gates, float* g_c_prev, int64_t M, int C, void* stream) {
+    SNN_REQUIRE(gates && c && g_gates && M > 0 && C > 0, "snn_lstm_cell_bwd: bad arguments");
+    hipLaunchKernelGGL(k_lstm_bwd, dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, gates, c_prev, c,
+                       gh, gc, g_gates, g_c_prev, M, C);
+    SNN_CHECK_LAUNCH("snn_lstm_cell_bwd");
     return 0;
 }
 

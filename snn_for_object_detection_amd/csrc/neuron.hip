@@ -201,7 +201,22 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                     lane<VEC>(o, j) = xj;
                 } else {
                     float vj = lane<VEC>(v, j), ij = lane<VEC>(i, j);
-                    float i_new = ij + xj;
+                    if (NEURON == SNN_NEURON_SYNAPSE) {
+                        const float tau = (xj > 0.0f) ? p.tau_sec : p.tau_dis;
+                        const float p_new = vj + ((xj - vj) * tau) * p.dt;
+                        float gsyn = p_new;
+                        if (p.sigma != 0.0f) gsyn = (4.0f * p.sigma) * (p_new - p.sigma * (p_new * p_new));
+                        lane<VEC>(v, j) = p_new;
+                        lane<VEC>(o, j) = gsyn < 0.0f ? 0.0f : gsyn;
+                        lane<VEC>(vd, j) = p_new;
+                        continue;
+                    }
+                    float xin = xj;
+                    if (NEURON == SNN_NEURON_SLI) {
+                        xin = xj * (1.0f / (1.0f + expf(-(p.v_st - fabsf(vj)))));
+                        lane<VEC>(vd, j) = vj;
+                    }
+                    float i_new = ij + xin;
                     float dv = p.c_mem * ((p.v_leak - vj) + i_new);
                     float v_dec = vj + dv;
                     float di = p.c_syn * i_new;
@@ -219,7 +234,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                 }
             }
             Vec<VEC>::store(out + row * ldo + c, o);
-            if (SAVE && NEURON == SNN_NEURON_LIF) Vec<VEC>::store(vdec + row * C + c, vd);
+            if (SAVE && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
+                Vec<VEC>::store(vdec + row * C + c, vd);
         }
         if (NEURON != SNN_NEURON_NONE) {
             if (vT) Vec<VEC>::store(vT + m * C + c, v);
@@ -286,11 +302,13 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
 template <int NEURON, int VEC, int MODE>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
-    int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ scale,
-    float* __restrict__ gx, float* __restrict__ g_v0, float* __restrict__ g_i0, double* __restrict__ sums, int T,
-    int64_t M, int C, int cvb, snn_neuron_params p) {
+    int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
+    const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
+    float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p) {
     typedef typename Vec<VEC>::type V;
     constexpr int NP = kBwdNP;
+    constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
+    constexpr bool kNeedsState = (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH || kNeedsX);
     extern __shared__ __attribute__((aligned(16))) float red[];  // MODE 1: [wave][T][cb][2]; MODE 2: [T][cb][2]
     const int cv = C / VEC;
     const int P = kThreads / cvb;
@@ -333,9 +351,23 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 if (ok[q]) {
                     const int64_t row = (int64_t)t * M + mq[q];
                     go[q] = Vec<VEC>::load(g_out + row * ldg + c);
-                    if (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH) st[q] = Vec<VEC>::load(state + row * C + c);
-                    if (MODE != 0) yv[q] = Vec<VEC>::load(y + row * ldy + c);
+                    if (kNeedsState) st[q] = Vec<VEC>::load(state + row * C + c);
+                    if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
                 }
+            }
+            V xa[NP];
+            if (kNeedsX) {  // x[t] = y[t]*alpha + beta, as the forward computed it
+                V a1, b1;
+                if (alpha) {
+                    a1 = Vec<VEC>::load(alpha + (int64_t)t * C + c);
+                    b1 = Vec<VEC>::load(beta + (int64_t)t * C + c);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        lane<VEC>(xa[q], j) = alpha ? lane<VEC>(yv[q], j) * lane<VEC>(a1, j) + lane<VEC>(b1, j)
+                                                    : lane<VEC>(yv[q], j);
             }
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -360,6 +392,28 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         lane<VEC>(gv[q], j) = g_vd * one_m_cmem;
                         lane<VEC>(gi[q], j) = g_in;
                         lane<VEC>(g, j) = g_in;
+                    } else if (NEURON == SNN_NEURON_SLI) {
+                        const float v_old = lane<VEC>(st[q], j);
+                        const float xj = lane<VEC>(xa[q], j);
+                        const float s = 1.0f / (1.0f + expf(-(p.v_st - fabsf(v_old))));
+                        const float sgn = (v_old > 0.0f) ? 1.0f : ((v_old < 0.0f) ? -1.0f : 0.0f);
+                        float g_vn = goj + lane<VEC>(gv[q], j);
+                        float g_ij = p.c_mem * g_vn + lane<VEC>(gi[q], j) * one_p_csyn;
+                        lane<VEC>(gv[q], j) = g_vn * one_m_cmem + g_ij * xj * (s * (1.0f - s)) * (-sgn);
+                        lane<VEC>(gi[q], j) = g_ij;
+                        lane<VEC>(g, j) = g_ij * s;
+                    } else if (NEURON == SNN_NEURON_SYNAPSE) {
+                        const float p_new = lane<VEC>(st[q], j);
+                        const float xj = lane<VEC>(xa[q], j);
+                        const float td = ((xj > 0.0f) ? p.tau_sec : p.tau_dis) * p.dt;
+                        float gpre = p_new, dg = 1.0f;
+                        if (p.sigma != 0.0f) {
+                            gpre = (4.0f * p.sigma) * (p_new - p.sigma * (p_new * p_new));
+                            dg = (4.0f * p.sigma) * (1.0f - 2.0f * p.sigma * p_new);
+                        }
+                        const float g_pn = goj * ((gpre >= 0.0f) ? dg : 0.0f) + lane<VEC>(gv[q], j);
+                        lane<VEC>(gv[q], j) = g_pn * (1.0f - td);
+                        lane<VEC>(g, j) = g_pn * td;
                     } else {
                         float d = 1.0f;
                         if (NEURON == SNN_NEURON_LI_TANH) {
@@ -377,8 +431,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         s2[j] += lane<VEC>(g, j) * lane<VEC>(yv[q], j);
                     }
                 }
-                if (scale) {
-                    V sc = Vec<VEC>::load(scale + (int64_t)t * C + c);
+                if (apply_scale) {
+                    V sc = Vec<VEC>::load(alpha + (int64_t)t * C + c);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
                 }
@@ -597,7 +651,7 @@ extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, co
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && ldo >= C, "snn_affine_neuron_fwd: bad shape");
     SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_affine_neuron_fwd: alpha/beta must come together");
-    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_LI_TANH, "snn_affine_neuron_fwd: bad neuron %d",
+    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_fwd: bad neuron %d",
                 neuron);
     int vec = (C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out) && aligned16(alpha) &&
                aligned16(beta) && aligned16(v0) && aligned16(i0) && aligned16(vT) && aligned16(iT) && aligned16(vdec))
@@ -614,7 +668,15 @@ extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, co
             else SNN_DISPATCH_FWD(SNN_NEURON_LIF, false);
             break;
         case SNN_NEURON_LI: SNN_DISPATCH_FWD(SNN_NEURON_LI, false); break;
-        default: SNN_DISPATCH_FWD(SNN_NEURON_LI_TANH, false); break;
+        case SNN_NEURON_LI_TANH: SNN_DISPATCH_FWD(SNN_NEURON_LI_TANH, false); break;
+        case SNN_NEURON_SLI:
+            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SLI, true);
+            else SNN_DISPATCH_FWD(SNN_NEURON_SLI, false);
+            break;
+        default:
+            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, true);
+            else SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, false);
+            break;
     }
     SNN_CHECK_LAUNCH("snn_affine_neuron_fwd");
     return 0;
@@ -628,8 +690,8 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
 
 #define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                                                                      \
     hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_>), grid, dim3(kThreads), pl.lds_bytes,           \
-                       (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, scale, gx, g_v0, g_i0, sums,  \
-                       T, M, C, pl.cvb, *p)
+                       (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, \
+                       g_v0, g_i0, sums, T, M, C, pl.cvb, *p)
 #define SNN_DISPATCH_BWD(NEURON)                                  \
     do {                                                          \
         if (pl.vec == 4) {                                        \
@@ -644,21 +706,25 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
     } while (0)
 
 extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state, const float* y,
-                                     int64_t ldy, const float* g_vT, const float* g_iT, const float* scale, float* gx,
-                                     float* g_v0, float* g_i0, double* sums, int T, int64_t M, int C,
-                                     const snn_neuron_params* p, void* stream) {
+                                     int64_t ldy, const float* g_vT, const float* g_iT, const float* alpha,
+                                     const float* beta, int apply_scale, float* gx, float* g_v0, float* g_i0,
+                                     double* sums, int T, int64_t M, int C, const snn_neuron_params* p,
+                                     void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
-    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_LI_TANH, "snn_affine_neuron_bwd: bad neuron %d",
+    SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_bwd: bad neuron %d",
                 neuron);
-    SNN_REQUIRE(!(neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI_TANH) || state,
+    const bool needs_x = neuron == SNN_NEURON_SLI || neuron == SNN_NEURON_SYNAPSE;
+    SNN_REQUIRE(!(neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI_TANH || needs_x) || state,
                 "snn_affine_neuron_bwd: saved state required");
-    SNN_REQUIRE(!sums || (y && ldy >= C), "snn_affine_neuron_bwd: y required for the BatchNorm sums");
+    SNN_REQUIRE(!(sums || needs_x) || (y && ldy >= C), "snn_affine_neuron_bwd: y required");
+    SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_affine_neuron_bwd: alpha/beta must come together");
+    SNN_REQUIRE(!apply_scale || alpha, "snn_affine_neuron_bwd: apply_scale needs alpha");
     BwdPlan pl = bwd_plan(T, M, C, sums != nullptr);
     if (pl.vec == 4) {
         bool ok = ldg % 4 == 0 && aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) &&
-                  aligned16(scale) && aligned16(gx) && aligned16(g_v0) && aligned16(g_i0) &&
-                  (!sums || (ldy % 4 == 0 && aligned16(y)));
+                  aligned16(alpha) && aligned16(beta) && aligned16(gx) && aligned16(g_v0) && aligned16(g_i0) &&
+                  (!(sums || needs_x) || (ldy % 4 == 0 && aligned16(y)));
         SNN_REQUIRE(ok, "snn_affine_neuron_bwd: buffers must be 16-byte aligned when C%%4==0");
     }
     dim3 grid(pl.gx, pl.gy);
@@ -666,7 +732,9 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
         case SNN_NEURON_NONE: SNN_DISPATCH_BWD(SNN_NEURON_NONE); break;
         case SNN_NEURON_LIF: SNN_DISPATCH_BWD(SNN_NEURON_LIF); break;
         case SNN_NEURON_LI: SNN_DISPATCH_BWD(SNN_NEURON_LI); break;
-        default: SNN_DISPATCH_BWD(SNN_NEURON_LI_TANH); break;
+        case SNN_NEURON_LI_TANH: SNN_DISPATCH_BWD(SNN_NEURON_LI_TANH); break;
+        case SNN_NEURON_SLI: SNN_DISPATCH_BWD(SNN_NEURON_SLI); break;
+        default: SNN_DISPATCH_BWD(SNN_NEURON_SYNAPSE); break;
     }
     SNN_CHECK_LAUNCH("snn_affine_neuron_bwd");
     return 0;

@@ -26,7 +26,9 @@ DEFAULT_DT = 0.001
 def neuron_params(dt: float = DEFAULT_DT) -> NeuronParams:
     tau_syn_inv = torch.as_tensor(1.0 / 5e-3)
     tau_mem_inv = torch.as_tensor(1.0 / 1e-2)
-    return NeuronParams((dt * tau_mem_inv).item(), (-dt * tau_syn_inv).item(), 0.0, 1.0, 0.0, 100.0)
+    # + SLI saturation potential (sli.py:38-39) and the synapse constants (synapse.py:26-36,77)
+    return NeuronParams((dt * tau_mem_inv).item(), (-dt * tau_syn_inv).item(), 0.0, 1.0, 0.0, 100.0,
+                        1.0, torch.as_tensor(1.0 / 1e-3).item(), torch.as_tensor(1.0 / 5e-3).item(), dt, 0.0)
 
 
 # ------------------------------------------------------------------------------------------- helpers
@@ -319,6 +321,14 @@ class NeuronState(NamedTuple):
     i: torch.Tensor
 
 
+class SynapseState(NamedTuple):
+    """State of a ``Synapse`` layer: mediator concentration (synapse.py:18-22)."""
+    p: torch.Tensor
+
+
+_SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
+
+
 class _AffineNeuron(Function):
     """[BatchNorm2d (per-timestep batch statistics)] -> [LIF | LI | LI+Tanh | nothing], fused.
 
@@ -364,7 +374,7 @@ class _AffineNeuron(Function):
         iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
         need_grad = any(ctx.needs_input_grad[:5])
         vdec = None
-        if neuron == _hip.NEURON_LIF and need_grad:
+        if neuron in _SAVES_STEP and need_grad:
             vdec = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
         if v0 is not None:
             v0 = _expand_state(v0, (B, C, H, W), dev)
@@ -379,8 +389,8 @@ class _AffineNeuron(Function):
         ctx.has_i0 = i0 is not None
         if neuron == _hip.NEURON_LI_TANH and need_grad and not is_channels_last(out):
             raise RuntimeError("LI+Tanh output placed in a concat slice is not supported for training")
-        state = vdec if neuron == _hip.NEURON_LIF else (out if neuron == _hip.NEURON_LI_TANH else None)
-        ctx.save_for_backward(y, gamma, mean, invstd, alpha, state)
+        state = vdec if neuron in _SAVES_STEP else (out if neuron == _hip.NEURON_LI_TANH else None)
+        ctx.save_for_backward(y, gamma, mean, invstd, alpha, beta, state)
         if not has_state:
             ctx.mark_non_differentiable(vT, iT)
         # with a neuron, vT / iT stay differentiable (time-outer BPTT through the carried state)
@@ -388,7 +398,7 @@ class _AffineNeuron(Function):
 
     @staticmethod
     def backward(ctx, g_out, g_vT, g_iT):
-        y, gamma, mean, invstd, alpha, state = ctx.saved_tensors
+        y, gamma, mean, invstd, alpha, beta, state = ctx.saved_tensors
         neuron, has_bn, use_running, params, (T, B, C, H, W) = ctx.cfg
         M = B * H * W
         st = _stream()
@@ -417,9 +427,10 @@ class _AffineNeuron(Function):
             n_sums = _hip.query("snn_affine_neuron_bwd_sums_size", T, M, C)
             sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
         # eval-mode BN has no batch coupling: dy = alpha * gx, applied while gx is written
-        scale = alpha if (has_bn and use_running) else None
+        apply_scale = 1 if (has_bn and use_running) else 0
         _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy, _ptr(g_vT),
-                  _ptr(g_iT), _ptr(scale), gx.data_ptr(), _ptr(g_v0), _ptr(g_i0), _ptr(sums), T, M, C, params, st)
+                  _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0), _ptr(sums),
+                  T, M, C, params, st)
         dy = dgamma = dbias = None
         if need_sums:
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)
@@ -482,11 +493,19 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             bn.num_batches_tracked.add_(seq.shape[0])
     v0 = i0 = None
     if state is not None:
-        v0, i0 = state
+        if neuron == _hip.NEURON_SYNAPSE:
+            (v0,) = state
+        else:
+            v0, i0 = state
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
            dest)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
-    new_state = NeuronState(vT, iT) if neuron != _hip.NEURON_NONE else None
+    if neuron == _hip.NEURON_NONE:
+        new_state = None
+    elif neuron == _hip.NEURON_SYNAPSE:
+        new_state = SynapseState(vT)
+    else:
+        new_state = NeuronState(vT, iT)
     return (out[0] if single else out), new_state
 
 
@@ -737,6 +756,65 @@ def upsample_nearest(x: torch.Tensor, scale: int) -> torch.Tensor:
     seq, single = as_sequence(x)
     y = _Upsample.apply(seq, int(scale))
     return y[0] if single else y
+
+
+# ------------------------------------------------------------------------------------------- ConvLSTM
+class _LstmCell(Function):
+    """Pointwise LSTM update on the gate pre-activations (conv_lstm.py:66-76); one timestep ``[B,*,H,W]``."""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        _require_device(gates, "lstm gates")
+        gates = _raw_dense_cl(gates)
+        B, C4, H, W = gates.shape
+        C = C4 // 4
+        if c_prev is not None:
+            c_prev = _raw_dense_cl(c_prev)
+        h = _new_cl((B,), C, H, W, gates)
+        c = _new_cl((B,), C, H, W, gates)
+        _hip.call("snn_lstm_cell_fwd", gates.data_ptr(), _ptr(c_prev), h.data_ptr(), c.data_ptr(), B * H * W, C,
+                  _stream())
+        ctx.save_for_backward(gates, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, gh, gc):
+        gates, c_prev, c = ctx.saved_tensors
+        B, C4, H, W = gates.shape
+        C = C4 // 4
+        gh = _raw_dense_cl(gh) if gh is not None else None
+        gc = _raw_dense_cl(gc) if gc is not None else None
+        g_gates = _new_cl((B,), C4, H, W, gates)
+        g_cp = _new_cl((B,), C, H, W, gates) if (c_prev is not None and ctx.needs_input_grad[1]) else None
+        _hip.call("snn_lstm_cell_bwd", gates.data_ptr(), _ptr(c_prev), c.data_ptr(), _ptr(gh), _ptr(gc),
+                  g_gates.data_ptr(), _ptr(g_cp), B * H * W, C, _stream())
+        return g_gates, g_cp
+
+
+def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]):
+    return _LstmCell.apply(gates, c_prev)
+
+
+class _StackTime(Function):
+    """``torch.stack`` over per-timestep ``[B,C,H,W]`` results into one channels-last ``[T,B,C,H,W]``."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_raw_to_cl(x) for x in xs]
+        B, C, H, W = xs[0].shape
+        out = _new_cl((len(xs), B), C, H, W, xs[0])
+        M, st = B * H * W, _stream()
+        for t, x in enumerate(xs):
+            _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out[t].data_ptr(), C, M, C, st)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[t] for t in range(g.shape[0]))
+
+
+def stack_time(xs: List[torch.Tensor]) -> torch.Tensor:
+    return _StackTime.apply(*xs)
 
 
 # ------------------------------------------------------------------------------------------- events

@@ -26,7 +26,7 @@ from . import functional as HF
 from .anchors import AnchorGenerator
 from .layer_gen import *  # noqa: F401,F403  (the reference re-exports the layer generators here)
 from .layer_gen import (Dense, HipBatchNorm2d, HipConv2d, HipTanh, LayerGen, LICell, LIFCell, Residual, Return,
-                        StateStorage, Storage)
+                        SLICell, StateStorage, Storage, SynapseCell)
 
 ListGen = List[Union[LayerGen, "ListGen"]]
 ListState = List[Union[torch.Tensor, None, "ListState"]]
@@ -39,7 +39,7 @@ def _is_module_stateful(m: nn.Module) -> bool:
 
 def _neuron_cell(layer: nn.Module) -> Optional[nn.Module]:
     cell = layer.module if isinstance(layer, StateStorage) else layer
-    return cell if isinstance(cell, (LIFCell, LICell)) else None
+    return cell if isinstance(cell, (LIFCell, LICell, SLICell, SynapseCell)) else None
 
 
 #####################################################################
@@ -191,7 +191,7 @@ class BlockGen(nn.Module):
                     Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise)
                 elif isinstance(layer, HipConv2d):
                     Y = layer(Y, dest=step_dest)
-                elif isinstance(layer, (LIFCell, LICell)):
+                elif isinstance(layer, (LIFCell, LICell, SLICell, SynapseCell)):
                     Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest)
                 elif flags[idx]:
                     Y, branch_state[idx] = layer(Y, branch_state[idx])

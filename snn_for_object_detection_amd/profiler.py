@@ -53,9 +53,9 @@ def work_of(name: str, a):
         elems = float(T) * M * C
         return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * (3 if save else 2)
     if name == "snn_affine_neuron_bwd":
-        neuron, T, M, C = a[0], a[13], a[14], a[15]
+        neuron, T, M, C = a[0], a[15], a[16], a[17]
         elems = float(T) * M * C
-        tensors = 2 + (1 if a[3] is not None else 0) + (1 if a[12] is not None else 0)
+        tensors = 2 + (1 if a[3] is not None else 0) + (1 if a[14] is not None else 0)
         return f"k_affine_neuron_bwd<{neuron}>", 16.0 * elems, 4.0 * elems * tensors
     if name == "snn_bn_stats":
         T, M, C = a[2], a[3], a[4]
