@@ -133,9 +133,10 @@ class SODa(nn.Module):
         _, _, num_classes = cls_preds.shape
         cls = self.cls_loss.forward(cls_preds.reshape(-1, num_classes), class_labels.reshape(-1))
         bbox = self.box_loss.forward(bbox_preds * bbox_mask, bbox_offset * bbox_mask)
-        mask = class_labels.reshape(-1) > 0
-        gt_loss = cls[mask].mean()
-        background_loss = cls[~mask].mean()
+        # masked means without boolean indexing (= cls[mask].mean(), cls[~mask].mean(); no host sync)
+        mask = (class_labels.reshape(-1) > 0).to(cls.dtype)
+        gt_loss = (cls * mask).sum() / mask.sum()
+        background_loss = (cls * (1 - mask)).sum() / (1 - mask).sum()
         return (gt_loss * self.hparams.loss_ratio + background_loss * (1 - self.hparams.loss_ratio) + bbox.mean())
 
     def spike_taps(self):
