@@ -88,13 +88,16 @@ int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, in
  * wgrad: dw[co,kh,kw,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n, ho*s-pad+kh, wo*s-pad+kw, ci]
  *        split over `splitk` pixel ranges into `workspace` ([splitk][Cout*KH*KW*Cin] floats),
  *        then reduced in fixed order (bitwise reproducible).
- * accumulate != 0 : the result is added to the destination instead of overwriting it. */
+ * fwd / dgrad `addend` (may be NULL): a tensor of the result's shape with pixel stride ld_addend that is added
+ *   in the epilogue (result = conv + addend); passing the destination itself accumulates in place.  This
+ *   fuses the gradient sum of a tensor consumed by several branches (generator.py:181-187) into the dgrad.
+ * wgrad accumulate != 0 : the result is added to dw instead of overwriting it. */
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                   int KH, int KW, int stride, int pad, int accumulate, void* stream);
+                   int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);
 int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                     int KH, int KW, int stride, int pad, int accumulate, void* stream);
+                     int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);
 int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, int accumulate,

@@ -57,7 +57,8 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 
 template <int BN, int WM, int WN, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
-                                                          float* __restrict__ out, ConvGeom g, int accumulate) {
+                                                          float* __restrict__ out, ConvGeom g,
+                                                          const float* __restrict__ addend, int64_t ld_add) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
@@ -258,10 +259,9 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
                         int64_t img = t / g.OHc;
                         pix = (img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
                     }
-                    float* p = out + pix * g.ldo + n;
                     float v = acc[i][j][e];
-                    if (accumulate) v += *p;
-                    *p = v;
+                    if (addend) v += addend[pix * ld_add + n];  // fused gradient accumulation (may alias out)
+                    out[pix * g.ldo + n] = v;
                 }
             }
         }
@@ -462,8 +462,8 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <bool DGRAD>
-static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, int accumulate,
-                         hipStream_t st, const char* name) {
+static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
+                         int64_t ld_add, hipStream_t st, const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(gm <= 0x7fffffff, "%s: too many pixels", name);
@@ -472,10 +472,10 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
         dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
         if (vec)                                                                                            \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true>), grid, dim3(kThreads), 0, st, in, \
-                               wk, out, g, accumulate);                                                     \
+                               wk, out, g, addend, ld_add);                                                 \
         else                                                                                                \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false>), grid, dim3(kThreads), 0, st,   \
-                               in, wk, out, g, accumulate);                                                 \
+                               in, wk, out, g, addend, ld_add);                                             \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
     else if (g.OC <= 64) SNN_CONV_LAUNCH(64, 2, 2);
@@ -503,7 +503,7 @@ static int check_conv_shape(const char* name, int64_t N, int H, int W, int Cin, 
 
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                              int accumulate, void* stream) {
+                              const float* addend, int64_t ld_addend, void* stream) {
     SNN_REQUIRE(x && w && y, "snn_conv2d_fwd: null pointer");
     if (check_conv_shape("snn_conv2d_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout, "snn_conv2d_fwd: pixel stride smaller than channel count");
@@ -518,15 +518,17 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
-    return launch_gather<false>(x, w, y, g, accumulate, (hipStream_t)stream, "snn_conv2d_fwd");
+    SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
+    return launch_gather<false>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
 extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                                int accumulate, void* stream) {
+                                const float* addend, int64_t ld_addend, void* stream) {
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(lddy >= Cout && lddx >= Cin, "snn_conv2d_dgrad: pixel stride smaller than channel count");
+    SNN_REQUIRE(!addend || ld_addend >= Cin, "snn_conv2d_dgrad: addend pixel stride smaller than channel count");
     ConvGeom g;
     g.IH = Ho; g.IW = Wo; g.IC = Cout;  // gathered tensor is dy
     g.OH = H; g.OW = W; g.OC = Cin;     // one GEMM row per INPUT pixel
@@ -547,7 +549,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = launch_gather<true>(dy, wt, dx, g, accumulate, (hipStream_t)stream, "snn_conv2d_dgrad");
+            int rc = launch_gather<true>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_dgrad");
             if (rc) return rc;
         }
     return 0;

@@ -247,6 +247,31 @@ class GradSlot:
         return acc
 
 
+class GradAccumulator:
+    """Shared by the aliases a block hands to its branches (``fanout``): lets the FIRST data-gradient
+    convolution that runs for the fanned-out tensor add the gradients other branches have already produced
+    in its epilogue (``snn_conv2d_dgrad(addend=...)``) instead of a separate add pass afterwards."""
+
+    __slots__ = ("deposits", "result", "fused")
+
+    def __init__(self):
+        self.deposits = {}    # alias index -> gradient produced for that alias by a pass-through consumer
+        self.result = None    # dx written by the fusing convolution
+        self.fused = {}       # alias index -> deposit that went into ``result``
+
+    def deposit(self, key, g: torch.Tensor) -> None:
+        if self.result is None and g is not None:
+            self.deposits[key] = g
+
+
+def _acc_of(x):
+    return getattr(x, "_snn_acc", None)
+
+
+def _same_tensor(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return (a.data_ptr() == b.data_ptr() and tuple(a.shape) == tuple(b.shape) and a.stride() == b.stride())
+
+
 def _slot_of(param) -> Optional[GradSlot]:
     return getattr(param, "_snn_grad_slot", None) if param is not None else None
 
@@ -256,7 +281,7 @@ class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None):
         _require_device(x, "conv2d input")
         _require_device(weight, "conv2d weight")
         T, B, Cin, H, W = _dims5(x)
@@ -270,10 +295,11 @@ class _Conv2d(Function):
         w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
         y = _out_tensor(dest, T, B, Cout, Ho, Wo, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
-                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, _stream())
+                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _stream())
         ctx.save_for_backward(x, w_ohwi)
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
         ctx.slot = slot
+        ctx.acc = acc
         return y
 
     @staticmethod
@@ -288,8 +314,20 @@ class _Conv2d(Function):
             wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
             _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
             dx = _new_cl((T, B), Cin, H, W, x)
+            addend, ld_add = None, 0
+            acc = ctx.acc
+            if acc is not None and acc[0].result is None and acc[0].deposits:
+                # another branch of the block already produced its gradient for this tensor: add it here
+                key, other = next(iter(acc[0].deposits.items()))
+                other = _raw_to_cl(other)
+                if tuple(other.shape) == tuple(dx.shape):
+                    addend, ld_add = other.data_ptr(), cl_stride(other)
+                    acc[0].fused[key] = acc[0].deposits.pop(key)
             _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
-                      Ho, Wo, Cout, KH, KW, stride, pad, 0, st)
+                      Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, st)
+            if acc is not None and acc[0].result is None:
+                acc[0].result = dx
+                acc[0].fused[acc[1]] = dx
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
             ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
@@ -301,13 +339,13 @@ class _Conv2d(Function):
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
                           W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
            dest: Optional[Dest] = None) -> torch.Tensor:
     seq, single = as_sequence(x)
-    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest)
+    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq))
     return y[0] if single else y
 
 
@@ -549,6 +587,7 @@ class _ConcatAssemble(Function):
     @staticmethod
     def forward(ctx, whole, *xs):
         ctx.widths = [x.shape[2] for x in xs]
+        ctx.accs = [_acc_of(x) for x in xs]
         T, B, C, H, W = _dims5(whole)
         return _alias(whole, whole.storage_offset(), T, B, C, H, W, cl_stride(whole))
 
@@ -557,7 +596,10 @@ class _ConcatAssemble(Function):
         g = _raw_to_cl(g)
         grads, off = [None], 0
         for k, c in enumerate(ctx.widths):
-            grads.append(g.narrow(2, off, c) if ctx.needs_input_grad[k + 1] else None)
+            gk = g.narrow(2, off, c) if ctx.needs_input_grad[k + 1] else None
+            if gk is not None and ctx.accs[k] is not None:
+                ctx.accs[k][0].deposit(ctx.accs[k][1], gk)
+            grads.append(gk)
             off += c
         return tuple(grads)
 
@@ -573,6 +615,7 @@ class _Sum(Function):
             if x.shape != xs[0].shape:
                 raise RuntimeError("Residual merge: branch outputs differ in shape")
         T, B, C, H, W = _dims5(xs[0])
+        ctx.accs = [_acc_of(x) for x in xs]
         out = _out_tensor(dest, T, B, C, H, W, xs[0])
         ldo, M, st = cl_stride(out), T * B * H * W, _stream()
         _hip.call("snn_add", xs[0].data_ptr(), cl_stride(xs[0]), xs[1].data_ptr(), cl_stride(xs[1]), out.data_ptr(),
@@ -583,6 +626,9 @@ class _Sum(Function):
 
     @staticmethod
     def backward(ctx, g):
+        for acc, need in zip(ctx.accs, ctx.needs_input_grad[1:]):
+            if acc is not None and need:
+                acc[0].deposit(acc[1], g)
         return (None,) + tuple(g if need else None for need in ctx.needs_input_grad[1:])
 
 
@@ -594,30 +640,58 @@ class _Fanout(Function):
 
     @staticmethod
     def forward(ctx, x, n: int):
+        ctx.acc = GradAccumulator()
+        ctx.outer = _acc_of(x)
         outs = []
-        for _ in range(n):
+        for k in range(n):
             t = torch.empty(0, device=x.device, dtype=x.dtype)
             t.set_(x.untyped_storage(), x.storage_offset(), x.size(), x.stride())
+            t._snn_acc = (ctx.acc, k)
             outs.append(t)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [g for g in gs if g is not None]
-        if not gs:
-            return None, None
-        if len(gs) == 1:
-            return gs[0], None
-        single = gs[0].dim() == 4
-        seqs = [_raw_to_cl(g.unsqueeze(0) if single else g) for g in gs]
-        T, B, C, H, W = _dims5(seqs[0])
-        out = _new_cl((T, B), C, H, W, seqs[0])
-        M, st = T * B * H * W, _stream()
-        _hip.call("snn_add", seqs[0].data_ptr(), cl_stride(seqs[0]), seqs[1].data_ptr(), cl_stride(seqs[1]),
-                  out.data_ptr(), C, M, C, st)
-        for g in seqs[2:]:
-            _hip.call("snn_add", out.data_ptr(), C, g.data_ptr(), cl_stride(g), out.data_ptr(), C, M, C, st)
-        return (out[0] if single else out), None
+        acc = ctx.acc
+        total = None
+        if acc.result is not None:
+            # a data-gradient convolution already holds (its own + the fused deposits'); add only what is missing
+            total = acc.result
+            for k, g in enumerate(gs):
+                if g is None:
+                    continue
+                if k in acc.fused:
+                    if not _same_tensor(g, acc.fused[k]):
+                        raise RuntimeError("fanout: a branch input received a gradient the fused accumulation did "
+                                           "not expect (the alias was consumed more than once)")
+                    continue
+                gk = _raw_to_cl(g)
+                T, B, C, H, W = _dims5(total)
+                _hip.call("snn_add", total.data_ptr(), C, gk.data_ptr(), cl_stride(gk), total.data_ptr(), C,
+                          T * B * H * W, C, _stream())
+        else:
+            live = [g for g in gs if g is not None]
+            if not live:
+                return None, None
+            if len(live) == 1:
+                total = live[0]
+            else:
+                single = live[0].dim() == 4
+                seqs = [_raw_to_cl(g.unsqueeze(0) if single else g) for g in live]
+                T, B, C, H, W = _dims5(seqs[0])
+                out = _new_cl((T, B), C, H, W, seqs[0])
+                M, st = T * B * H * W, _stream()
+                _hip.call("snn_add", seqs[0].data_ptr(), cl_stride(seqs[0]), seqs[1].data_ptr(), cl_stride(seqs[1]),
+                          out.data_ptr(), C, M, C, st)
+                for g in seqs[2:]:
+                    _hip.call("snn_add", out.data_ptr(), C, g.data_ptr(), cl_stride(g), out.data_ptr(), C, M, C, st)
+                total = out[0] if single else out
+        acc.deposits.clear()
+        acc.fused.clear()
+        acc.result = None
+        if ctx.outer is not None:
+            ctx.outer[0].deposit(ctx.outer[1], total)
+        return total, None
 
 
 def fanout(x: torch.Tensor, n: int):
@@ -632,6 +706,7 @@ class _Place(Function):
 
     @staticmethod
     def forward(ctx, x, dest):
+        ctx.acc = _acc_of(x)
         x = _raw_to_cl(x)
         T, B, C, H, W = _dims5(x)
         out = dest.tensor(T, B, C, H, W, x)
@@ -641,6 +716,8 @@ class _Place(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.acc is not None:
+            ctx.acc[0].deposit(ctx.acc[1], g)
         return g, None
 
 
