@@ -378,6 +378,7 @@ class _AffineNeuron(Function):
     def forward(ctx, y, gamma, bias, v0, i0, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest) = cfg
         _require_device(y, "norm/neuron input")
+        ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
         ldy = cl_stride(y)
         T, B, C, H, W = _dims5(y)
