@@ -341,13 +341,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 if (g_iT) gi[q] = Vec<VEC>::load(g_iT + mq[q] * C + c);
             }
         }
-        for (int t = T - 1; t >= 0; --t) {
-            float s1[VEC], s2[VEC];
+        // Two register sets: the loads of timestep t-1 are in flight while timestep t is processed.
+        auto fetch = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
-            V go[NP], st[NP], yv[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {  // issue every load of this timestep first
+            for (int q = 0; q < NP; ++q) {
                 if (ok[q]) {
                     const int64_t row = (int64_t)t * M + mq[q];
                     go[q] = Vec<VEC>::load(g_out + row * ldg + c);
@@ -355,6 +352,11 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
                 }
             }
+        };
+        auto process = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
+            float s1[VEC], s2[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
             V xa[NP];
             if (kNeedsX) {  // x[t] = y[t]*alpha + beta, as the forward computed it
                 V a1, b1;
@@ -465,6 +467,16 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         atomicAdd(r + j * 2 + 1, s2[j]);
                     }
                 }
+            }
+                };
+        V goA[NP], stA[NP], yvA[NP], goB[NP], stB[NP], yvB[NP];
+        fetch(T - 1, goA, stA, yvA);
+        for (int t = T - 1; t >= 0; t -= 2) {
+            if (t >= 1) fetch(t - 1, goB, stB, yvB);
+            process(t, goA, stA, yvA);
+            if (t >= 1) {
+                if (t >= 2) fetch(t - 2, goA, stA, yvA);
+                process(t - 1, goB, stB, yvB);
             }
         }
         if (NEURON != SNN_NEURON_NONE) {
