@@ -158,11 +158,15 @@ def main():
     roofline = None
     if not args.no_roofline:
         # every rank runs the two extra steps (they contain the all-reduce); only rank 0 brackets its launches
+        # kernels are timed one at a time: the weight-gradient side stream is switched off for these two steps
+        from snn_for_object_detection_amd import functional as HF
         prof = KernelProfiler() if rank == 0 else None
         _hip.PROFILER = prof
+        HF.USE_WGRAD_STREAM = False
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        HF.USE_WGRAD_STREAM = True
         _hip.PROFILER = None
     if rank == 0 and not args.no_roofline:
         table = prof.summary()

@@ -36,6 +36,26 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Weight gradients do not feed the rest of the backward pass, so they run on a second HIP stream beside the
+# data-gradient chain (fills the CUs that small feature maps leave idle).  ``wgrad_stream_sync()`` joins the
+# side stream; trainer.FlatTrainer.step() calls it before the all-reduce / optimiser read the gradients.
+_SIDE_STREAMS = {}
+USE_WGRAD_STREAM = True
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def wgrad_stream_sync() -> None:
+    """Make the current stream wait for every weight-gradient kernel queued on the side stream."""
+    for dev, st in _SIDE_STREAMS.items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -330,11 +350,24 @@ class _Conv2d(Function):
                 acc[0].fused[acc[1]] = dx
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
-            ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
-            if ctx.slot is not None:
+            if ctx.slot is not None and USE_WGRAD_STREAM:
+                # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
+                # the kernel runs on the side stream, concurrently with the data-gradient chain
+                main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                side.wait_stream(main)  # gy (and every earlier use of the slot) is complete
+                with torch.cuda.stream(side):
+                    ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
+                    _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(),
+                              T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(),
+                              splitk, side.cuda_stream)
+                x.record_stream(side)
+                gy.record_stream(side)
+            elif ctx.slot is not None:
+                ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(), T * B,
                           H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, st)
             else:
+                ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
                           W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)

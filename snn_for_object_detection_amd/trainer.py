@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
-from .functional import GradSlot
+from .functional import GradSlot, wgrad_stream_sync
 
 
 def _storage_view(flat: torch.Tensor, offset: int, like: torch.Tensor) -> torch.Tensor:
@@ -77,6 +77,8 @@ class FlatTrainer:
 
     # ------------------------------------------------------------------
     def zero_grad(self) -> None:
+        if self.flat_grad.is_cuda:
+            wgrad_stream_sync()  # nothing may still be writing into the buffer that is about to be cleared
         self.flat_grad.zero_()
         for p, slot in zip(self.params, self.slots):
             slot.written = False
@@ -99,6 +101,8 @@ class FlatTrainer:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self) -> None:
+        if self.flat_param.is_cuda:
+            wgrad_stream_sync()  # weight-gradient kernels run on a side stream (functional._Conv2d.backward)
         self._collect_autograd_grads()
         self.all_reduce()
         self.step_count += 1
@@ -112,11 +116,18 @@ class FlatTrainer:
                                "CPU fallback")
 
     # ------------------------------------------------------------------ helpers for tests / checkpoints
+    def synchronize(self) -> None:
+        """Join the weight-gradient side stream: after this the current stream may read ``flat_grad``."""
+        if self.flat_grad.is_cuda:
+            wgrad_stream_sync()
+
     def averaged_grad(self) -> torch.Tensor:
         """The (all-reduced) flat gradient divided by world_size, as the optimiser sees it."""
+        self.synchronize()
         return self.flat_grad[: self.numel] / self.world
 
     def grads_by_name(self, model: torch.nn.Module):
+        self.synchronize()
         names = [n for n, p in model.named_parameters() if p.requires_grad]
         return {n: g for n, g in zip(names, self.grad_views)}
 

@@ -49,6 +49,7 @@ def test_fullsize_step_is_deterministic(S):
         tr.zero_grad()
         loss = model.training_step((X, labels))
         loss.backward()
+        tr.synchronize()
         results.append((loss.detach().clone(), tr.flat_grad.clone()))
         del model, tr
     assert torch.equal(results[0][0], results[1][0])
