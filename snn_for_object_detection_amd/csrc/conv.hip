@@ -9,14 +9,17 @@
 //       m = output pixel (img, oy, ox); k = (tap, c); n = output channel
 //       FWD  : A = x [img][oy*s-pad+kh][ox*s-pad+kw][c],             Wk = w  [Cout][taps][Cin]
 //       DGRAD: A = dy[img][(oy+pad-kh)/s][(ox+pad-kw)/s][c] (exact), Wk = wt [Cin][taps][Cout]
-//     block tile 128 pixels x BN channels x 32 k, 4 waves; LDS images [row][32+4] fp32 read
-//     with ds_read_b128 (the +4 pad makes the four 16-lane groups conflict-free); global ->
-//     register prefetch of tile k+1 overlaps the MFMAs of tile k.
+//     block tile 128 pixels x BN channels x 32 k, 4 waves, 3 blocks / CU; LDS images [row][32+4] fp32 read
+//     with ds_read_b128 (the +4 pad makes the four 16-lane groups conflict-free); branch-free global ->
+//     register prefetch of tile k+1 (clamped addresses + select) overlaps the MFMAs of tile k; the data
+//     gradient of a strided conv is split into stride x stride phase classes that only visit reachable taps;
+//     the epilogue can add a same-shaped tensor (fused gradient accumulation).
 //
 //   weight-gradient:
 //       dw[co][kc] = sum_pix dy[pix][co] * xg[pix][kc],  kc = (tap, ci)
-//     block tile 64 x 64 over (co, kc), K = pixels, split over gridDim.z pixel ranges into
-//     workspace slabs, reduced in fixed order by k_wgrad_reduce (bitwise reproducible).
+//     block tile up to 128 x 128 over (co, kc) (six variants, least padding wins), K = pixels, split over
+//     pixel ranges sized to ONE resident wave of blocks, splits pinned to XCDs (L2 reuse of dy / x),
+//     workspace slabs reduced in fixed order by k_wgrad_reduce (bitwise reproducible).
 //
 // fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what the 1e-4
 // parity target against the CPU reference needs.
@@ -28,13 +31,8 @@ constexpr int kThreads = 256;
 constexpr int BM = 128;  // output pixels per block
 constexpr int BK = 32;   // k elements per LDS stage
 constexpr int LDK = BK + 4;
-#ifndef SNN_CONV_LDS_STAGES
-#define SNN_CONV_LDS_STAGES 1
-#endif
-#ifndef SNN_CONV_MIN_WAVES
+// 3 waves / SIMD (<= 168 VGPRs): measured +5..+25 % over 2 waves / SIMD with a second LDS stage
 #define SNN_CONV_MIN_WAVES 3
-#endif
-constexpr int NSTAGE = SNN_CONV_LDS_STAGES;
 
 struct ConvGeom {
     int64_t Mtot;      // GEMM rows: img * OH * OW (FWD) or img * OHc * OWc (DGRAD, one stride-phase class)
@@ -63,10 +61,8 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    // two LDS stages: the MFMAs of stage k read buffer k&1 while the prefetched tile k+1 is written to the
-    // other buffer, so one barrier per k-step suffices
-    __shared__ __attribute__((aligned(16))) float As[NSTAGE][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -122,13 +118,6 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 
     auto load_tiles = [&](int k0) {
         const int kk = k0 + kq;
-#ifdef SNN_ABL_NOLOAD
-        if (k0 > 0) {  // timing ablation only: keep the first tile, skip every later global load
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j][0] += 1.0f;
-            return;
-        }
-#endif
         if (VEC) {
             // Branch-free: every lane always loads from a clamped (valid) address and masks the value afterwards,
             // so the whole k-step stays one basic block and the scheduler can interleave these loads with MFMAs.
@@ -174,11 +163,11 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[buf][(lr + 32 * j) * LDK + kq]) = ra[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[(lr + 32 * j) * LDK + kq]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(lr + 32 * j) * LDK + kq]) = rb[j];
+        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * j) * LDK + kq]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -191,20 +180,19 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 
     if (g.Ktot > 0) {  // a dgrad stride-phase class may have no tap at all: its pixels are plain zeros
         load_tiles(0);
-        store_tiles(0);
+        store_tiles();
     }
     __syncthreads();
 
     // Branch-free steady state (a tile past Ktot loads zeros and is never read): keeping the MFMA chain in
     // one basic block lets the accumulators stay in their registers across iterations.
-    int cur = 0;
 #pragma unroll 1
     for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
         load_tiles(k0 + BK);
         // keep the prefetch ahead of the MFMA chain: its latency must be covered by the whole k-step
         __builtin_amdgcn_sched_barrier(0);
-        const float* Ac = As[cur];
-        const float* Bc = Bs[cur];
+        const float* Ac = As;
+        const float* Bc = Bs;
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             f32x4 a[TM], b[TN];
@@ -214,12 +202,6 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(&Bc[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
-#ifdef SNN_ABL_NOMFMA
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][0] += a[i][0] * b[j][0] + a[i][1] * b[j][1] + a[i][2] * b[j][2] + a[i][3] * b[j][3];
-#else
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -227,17 +209,10 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-#endif
         }
-        if (NSTAGE == 2) {
-            store_tiles(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        } else {
-            __syncthreads();
-            store_tiles(0);
-            __syncthreads();
-        }
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
