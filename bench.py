@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--height", type=int, default=GEN1_H)
     ap.add_argument("--width", type=int, default=GEN1_W)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
@@ -124,6 +126,9 @@ def main():
     model = S.TinyYolo(num_classes=args.classes, time_window=0).to(device).train()
     trainer = FlatTrainer(model, lr=model.hparams.learning_rate)
     broadcast_parameters(trainer)
+    if args.sync_bn and world > 1:
+        from snn_for_object_detection_amd.trainer import convert_sync_batchnorm
+        convert_sync_batchnorm(model)
     X, labels = synthetic_batch(T, B, H, W, args.classes, device, seed=rank)  # a different shard per rank
 
     def step():
@@ -218,6 +223,7 @@ def main():
                 "workload": f"SODa/TinyYolo (4.23M params) GEN1 {W}x{H}, B={B}/GPU T={T}, p(event)=0.05, 2 boxes/sample, "
                             "fwd + loss(last step) + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
+                "sync_batchnorm": bool(args.sync_bn and world > 1),
                 "loss": float(loss.item()),
             },
             "roofline": roofline,

@@ -120,6 +120,16 @@ int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C,
                           float* running_mean, float* running_var, int use_running,
                           float* mean, float* invstd, float* alpha, float* beta, void* stream);
 
+/* SyncBatchNorm form (config.yaml:76) of the two steps above: reduce the chunk partials to sums[T][C][2]
+ * (sum y, sum y^2), let the caller all-reduce that small tensor over the ranks, then finish from the global
+ * sums over M_total = world * M pixels.  var_scratch: T*C doubles. */
+int snn_bn_stats_reduce(const double* partial, int T, int64_t M, int C, double* sums, void* stream);
+int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total, int C,
+                           const float* gamma, const float* bias, float eps, float momentum,
+                           float* running_mean, float* running_var,
+                           float* mean, float* invstd, float* alpha, float* beta,
+                           double* var_scratch, void* stream);
+
 /* ---------------------------------------------------------------- fused affine + neuron scan
  * One kernel = BatchNorm apply + T-step neuron recurrence with the membrane state held in
  * registers.  Replaces, per layer, T x {BatchNorm2d apply, ~12 elementwise norse ops}
@@ -165,6 +175,14 @@ int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C,
                         const float* gamma, const float* mean, const float* invstd,
                         float* coefA, float* coefB, float* coefC,
                         float* dgamma, float* dbias, int accumulate, void* stream);
+/* The same in two steps for SyncBatchNorm: raw[T][C][2] = (sum gx, sum gx*y) of this rank; the caller
+ * all-reduces a copy; coefficients come from the global sums over M_total pixels while dgamma / dbias use
+ * the rank-local sums (DDP averages them afterwards).  param_sums: T*C*2 doubles of scratch. */
+int snn_bn_bwd_reduce(const double* sums, int T, int64_t M, int C, double* raw, void* stream);
+int snn_bn_bwd_coef(const double* raw, const double* raw_local, double* param_sums, int T, int64_t M_total, int C,
+                    const float* gamma, const float* mean, const float* invstd,
+                    float* coefA, float* coefB, float* coefC,
+                    float* dgamma, float* dbias, int accumulate, void* stream);
 int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy,
                      const float* coefA, const float* coefB, const float* coefC,
                      float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate, void* stream);

@@ -40,6 +40,10 @@ SIGNATURES = {
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
     "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_bn_stats_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "snn_bn_stats_reduce": (c_int, [_P, _I, _L, _I, _P, _P]),
+    "snn_bn_stats_from_sums": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "snn_bn_bwd_reduce": (c_int, [_P, _I, _L, _I, _P, _P]),
+    "snn_bn_bwd_coef": (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),
     "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),

@@ -139,6 +139,22 @@ __global__ void k_bn_stats_finalize(const double* __restrict__ partial, int chun
     beta[idx] = b - mu * a;
 }
 
+// chunk partials -> sums[t][c][2] (the quantity a SyncBatchNorm exchange all-reduces, config.yaml:76)
+__global__ void k_bn_stats_reduce(const double* __restrict__ partial, int chunks, int T, int C,
+                                  double* __restrict__ sums) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * C) return;
+    int t = idx / C, c = idx % C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
+        s += src[0];
+        q += src[1];
+    }
+    sums[(int64_t)idx * 2 + 0] = s;
+    sums[(int64_t)idx * 2 + 1] = q;
+}
+
 // T sequential running-stat updates of one reference forward (one BatchNorm call per timestep).
 __global__ void k_bn_running_update(const float* __restrict__ mean, const double* __restrict__ var_unbiased, int T,
                                     int C, float momentum, float* __restrict__ running_mean,
@@ -514,13 +530,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     }
 }
 
-// reduce block partials -> per (t,c) S1 = sum gx, S2 = sum gx*xhat (kept in block 0's slot), emit coefficients.
-// 32 lanes per (t,c): lane k sums blocks k, k+32, ... then a fixed xor tree combines the lanes.
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(double* __restrict__ sums, int gx_blocks, int T, int64_t M,
-                                                         int C, const float* __restrict__ gamma,
-                                                         const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ coefA,
-                                                         float* __restrict__ coefB, float* __restrict__ coefC) {
+// reduce block partials -> raw[t][c] = (sum gx, sum gx*y).  32 lanes per (t,c): lane k sums blocks k, k+32, ...
+// then a fixed xor tree combines the lanes.  `raw` may be the partial buffer itself (block 0's slot).
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict__ sums, int gx_blocks, int T, int C,
+                                                       double* __restrict__ raw) {
     const int sub = threadIdx.x & 31;
     const int idx = blockIdx.x * (blockDim.x / 32) + (threadIdx.x >> 5);
     const bool live = idx < T * C;
@@ -538,17 +551,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(double* __restrict__ su
     }
     __syncthreads();  // every partial of this block's (t,c) pairs has been read before slot 0 is rewritten
     if (!live || sub != 0) return;
+    raw[(int64_t)idx * 2 + 0] = s1;
+    raw[(int64_t)idx * 2 + 1] = sy;
+}
+
+// raw sums over M pixels (all-reduced over the ranks under SyncBatchNorm) -> backward coefficients;
+// raw_local (this rank's sums) -> (sum gx, sum gx*xhat) for the parameter gradients, written to `param_sums`
+__global__ void k_bn_bwd_coef(const double* __restrict__ raw, const double* __restrict__ raw_local, int T, int64_t M,
+                              int C, const float* __restrict__ gamma, const float* __restrict__ mean,
+                              const float* __restrict__ invstd, float* __restrict__ coefA, float* __restrict__ coefB,
+                              float* __restrict__ coefC, double* __restrict__ param_sums) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * C) return;
     const int c = idx % C;
-    double mu = (double)mean[idx], is = (double)invstd[idx];
-    double s2 = is * (sy - mu * s1);  // sum gx * xhat
-    sums[(int64_t)idx * 2 + 0] = s1;
-    sums[(int64_t)idx * 2 + 1] = s2;
-    double n = (double)M;
-    double a = (double)(gamma ? gamma[c] : 1.0f) * is;
-    double m1 = s1 / n, m2 = s2 / n;
+    const double mu = (double)mean[idx], is = (double)invstd[idx];
+    const double s1 = raw[(int64_t)idx * 2 + 0], sy = raw[(int64_t)idx * 2 + 1];
+    const double l1 = raw_local[(int64_t)idx * 2 + 0], ly = raw_local[(int64_t)idx * 2 + 1];
+    const double s2 = is * (sy - mu * s1);  // sum gx * xhat
+    const double n = (double)M;
+    const double a = (double)(gamma ? gamma[c] : 1.0f) * is;
+    const double m1 = s1 / n, m2 = s2 / n;
     coefA[idx] = (float)a;
     coefB[idx] = (float)(-a * is * m2);
     coefC[idx] = (float)(-a * m1 + a * is * mu * m2);
+    param_sums[(int64_t)idx * 2 + 0] = l1;
+    param_sums[(int64_t)idx * 2 + 1] = is * (ly - mu * l1);
 }
 
 __global__ void k_bn_bwd_params(const double* __restrict__ sums, int T, int C, float* __restrict__ dgamma,
@@ -642,6 +669,35 @@ extern "C" int snn_bn_stats_finalize(const double* partial, int T, int64_t M, in
     if (!use_running && running_mean && running_var) {
         hipLaunchKernelGGL(k_bn_running_update, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean,
                            var_unbiased, T, C, momentum, running_mean, running_var);
+        SNN_CHECK_LAUNCH("snn_bn_running_update");
+    }
+    return 0;
+}
+
+extern "C" int snn_bn_stats_reduce(const double* partial, int T, int64_t M, int C, double* sums, void* stream) {
+    SNN_REQUIRE(partial && sums && T > 0 && M > 0 && C > 0, "snn_bn_stats_reduce: bad arguments");
+    StatsPlan pl = stats_plan(T, M, C);
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_stats_reduce, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, pl.chunks,
+                       T, C, sums);
+    SNN_CHECK_LAUNCH("snn_bn_stats_reduce");
+    return 0;
+}
+
+extern "C" int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total, int C, const float* gamma,
+                                      const float* bias, float eps, float momentum, float* running_mean,
+                                      float* running_var, float* mean, float* invstd, float* alpha, float* beta,
+                                      double* var_scratch, void* stream) {
+    SNN_REQUIRE(sums && mean && invstd && alpha && beta && var_scratch, "snn_bn_stats_from_sums: null pointer");
+    SNN_REQUIRE(T > 0 && M_total > 0 && C > 0, "snn_bn_stats_from_sums: bad shape");
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_stats_finalize, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, 1, T,
+                       M_total, C, gamma, bias, eps, running_mean, running_var, 0, mean, invstd, alpha, beta,
+                       var_scratch);
+    SNN_CHECK_LAUNCH("snn_bn_stats_from_sums");
+    if (running_mean && running_var) {
+        hipLaunchKernelGGL(k_bn_running_update, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean,
+                           var_scratch, T, C, momentum, running_mean, running_var);
         SNN_CHECK_LAUNCH("snn_bn_running_update");
     }
     return 0;
@@ -752,22 +808,43 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     return 0;
 }
 
-extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const float* gamma, const float* mean,
-                                   const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
-                                   float* dbias, int accumulate, void* stream) {
-    SNN_REQUIRE(sums && mean && invstd && coefA && coefB && coefC, "snn_bn_bwd_finalize: null pointer");
-    SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_bwd_finalize: bad shape");
+extern "C" int snn_bn_bwd_reduce(const double* sums, int T, int64_t M, int C, double* raw, void* stream) {
+    SNN_REQUIRE(sums && raw && T > 0 && M > 0 && C > 0, "snn_bn_bwd_reduce: bad arguments");
     BwdPlan pl = bwd_plan(T, M, C, true);
     int n = T * C;
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, M,
-                       C, gamma, mean, invstd, coefA, coefB, coefC);
-    SNN_CHECK_LAUNCH("snn_bn_bwd_finalize");
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, C, raw);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int snn_bn_bwd_coef(const double* raw, const double* raw_local, double* param_sums, int T, int64_t M_total,
+                               int C, const float* gamma, const float* mean, const float* invstd, float* coefA,
+                               float* coefB, float* coefC, float* dgamma, float* dbias, int accumulate,
+                               void* stream) {
+    SNN_REQUIRE(raw && raw_local && param_sums && mean && invstd && coefA && coefB && coefC,
+                "snn_bn_bwd_coef: null pointer");
+    SNN_REQUIRE(T > 0 && M_total > 0 && C > 0, "snn_bn_bwd_coef: bad shape");
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_bwd_coef, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, raw_local, T,
+                       M_total, C, gamma, mean, invstd, coefA, coefB, coefC, param_sums);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_coef");
     if (dgamma || dbias) {
-        hipLaunchKernelGGL(k_bn_bwd_params, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, T, C,
+        hipLaunchKernelGGL(k_bn_bwd_params, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, param_sums, T, C,
                            dgamma, dbias, accumulate);
         SNN_CHECK_LAUNCH("snn_bn_bwd_params");
     }
     return 0;
+}
+
+// single-process form: reduce the block partials in place, then coefficients and parameter gradients
+extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const float* gamma, const float* mean,
+                                   const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                   float* dbias, int accumulate, void* stream) {
+    SNN_REQUIRE(sums && mean && invstd && coefA && coefB && coefC, "snn_bn_bwd_finalize: null pointer");
+    int rc = snn_bn_bwd_reduce(sums, T, M, C, sums, stream);
+    if (rc) return rc;
+    return snn_bn_bwd_coef(sums, sums, sums, T, M, C, gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbias,
+                           accumulate, stream);
 }
 
 extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, const float* coefA, const float* coefB,

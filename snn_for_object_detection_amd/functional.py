@@ -409,7 +409,8 @@ class _AffineNeuron(Function):
 
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, cfg):
-        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest) = cfg
+        (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
+         sync_group) = cfg
         _require_device(y, "norm/neuron input")
         ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
@@ -437,9 +438,21 @@ class _AffineNeuron(Function):
                 n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
                 partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
                 _hip.call("snn_bn_stats", y.data_ptr(), ldy, T, M, C, partial.data_ptr(), st)
-                _hip.call("snn_bn_stats_finalize", partial.data_ptr(), T, M, C, g_ptr, b_ptr, eps, momentum,
-                          _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
-                          alpha.data_ptr(), beta.data_ptr(), st)
+                if sync_group is None:
+                    _hip.call("snn_bn_stats_finalize", partial.data_ptr(), T, M, C, g_ptr, b_ptr, eps, momentum,
+                              _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
+                              alpha.data_ptr(), beta.data_ptr(), st)
+                else:
+                    # SyncBatchNorm (config.yaml:76): ONE all-reduce of [T, C, 2] sums per layer for all timesteps
+                    import torch.distributed as dist
+                    world = dist.get_world_size(sync_group[0])
+                    sums = torch.empty((T, C, 2), device=dev, dtype=torch.float64)
+                    _hip.call("snn_bn_stats_reduce", partial.data_ptr(), T, M, C, sums.data_ptr(), st)
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=sync_group[0])
+                    scratch = torch.empty((T * C,), device=dev, dtype=torch.float64)
+                    _hip.call("snn_bn_stats_from_sums", sums.data_ptr(), T, M * world, C, g_ptr, b_ptr, eps, momentum,
+                              _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                              alpha.data_ptr(), beta.data_ptr(), scratch.data_ptr(), st)
         out = _out_tensor(dest, T, B, C, H, W, y)
         has_state = neuron != _hip.NEURON_NONE
         vT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
@@ -457,6 +470,7 @@ class _AffineNeuron(Function):
                   _ptr(vdec), T, M, C, params, st)
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
+        ctx.sync_group = sync_group if (has_bn and not use_running) else None
         ctx.has_v0 = v0 is not None
         ctx.has_i0 = i0 is not None
         if neuron == _hip.NEURON_LI_TANH and need_grad and not is_channels_last(out):
@@ -508,22 +522,36 @@ class _AffineNeuron(Function):
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)
             g_slot, b_slot = ctx.slots
             slotted = (g_slot is not None or not need_gamma) and (b_slot is not None or not need_bias)
+            acc_flag = 0
             if slotted and (need_gamma or need_bias):
                 # gradients go straight into the flat gradient buffer; both share one accumulate flag
-                acc = (g_slot or b_slot).written
+                acc_flag = 1 if (g_slot or b_slot).written else 0
                 for s_ in (g_slot, b_slot):
                     if s_ is not None:
                         s_.claim()
-                _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
-                          invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
-                          g_slot.buf.data_ptr() if (g_slot is not None and need_gamma) else None,
-                          b_slot.buf.data_ptr() if (b_slot is not None and need_bias) else None, 1 if acc else 0, st)
+                dg_ptr = g_slot.buf.data_ptr() if (g_slot is not None and need_gamma) else None
+                db_ptr = b_slot.buf.data_ptr() if (b_slot is not None and need_bias) else None
             else:
                 dgamma = torch.empty((C,), device=dev, dtype=_F32) if need_gamma else None
                 dbias = torch.empty((C,), device=dev, dtype=_F32) if need_bias else None
+                dg_ptr, db_ptr = _ptr(dgamma), _ptr(dbias)
+            if ctx.sync_group is None:
                 _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
-                          invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
-                          _ptr(dgamma), _ptr(dbias), 0, st)
+                          invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), dg_ptr,
+                          db_ptr, acc_flag, st)
+            else:
+                # SyncBatchNorm backward: dy needs the GLOBAL sums (one all-reduce of [T, C, 2]); the parameter
+                # gradients use the rank-local sums - the data-parallel all-reduce averages them afterwards
+                import torch.distributed as dist
+                world = dist.get_world_size(ctx.sync_group[0])
+                raw_local = torch.empty((T, C, 2), device=dev, dtype=torch.float64)
+                _hip.call("snn_bn_bwd_reduce", sums.data_ptr(), T, M, C, raw_local.data_ptr(), st)
+                raw = raw_local.clone()
+                dist.all_reduce(raw, op=dist.ReduceOp.SUM, group=ctx.sync_group[0])
+                param_sums = torch.empty((T, C, 2), device=dev, dtype=torch.float64)
+                _hip.call("snn_bn_bwd_coef", raw.data_ptr(), raw_local.data_ptr(), param_sums.data_ptr(), T, M * world,
+                          C, _ptr(gamma), mean.data_ptr(), invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                          coef[2].data_ptr(), dg_ptr, db_ptr, acc_flag, st)
             if need_y and not use_running:
                 # in place: dy overwrites gx
                 _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), ldy, coef[0].data_ptr(),
@@ -569,8 +597,9 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             (v0,) = state
         else:
             v0, i0 = state
+    sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
-           dest)
+           dest, sync_group)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
     if neuron == _hip.NEURON_NONE:
         new_state = None

@@ -132,6 +132,22 @@ class FlatTrainer:
         return {n: g for n, g in zip(names, self.grad_views)}
 
 
+def convert_sync_batchnorm(model: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """Opt-in equivalent of Lightning's ``sync_batchnorm: true`` (config/config.yaml:76).
+
+    Every BatchNorm of ``model`` then normalises with statistics of the GLOBAL batch.  Thanks to the layer-major
+    schedule the exchange is ONE all-reduce of a ``[T, C, 2]`` fp64 tensor per BatchNorm layer in forward and
+    one in backward (44 per step for TinyYolo) instead of one per layer per timestep (1 408 at T = 32).
+    Default (not converted): statistics and running buffers are rank-local.
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("convert_sync_batchnorm needs an initialised process group")
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m._snn_sync_group = (process_group,)
+    return model
+
+
 def broadcast_parameters(trainer: FlatTrainer, src: int = 0) -> None:
     """Make every rank start from rank ``src``'s weights (DDP does this at construction)."""
     if trainer.world > 1:

@@ -1,0 +1,79 @@
+"""SyncBatchNorm mode (config/config.yaml:76) on the device: two ranks, each with half of the batch, must
+reproduce the single-process full-batch result of the fused Norm+LIF block (outputs, input gradients; the sum
+of the rank-local weight gradients equals the full-batch weight gradient).  Both ranks share the one GPU of the
+test box and exchange through gloo - the production transport is RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg():
+    from snn_for_object_detection_amd import Conv, LIF, Norm
+    return [Conv(8, 3), Norm(), LIF(), Conv(4, 1), Norm(bias=True)]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import convert_sync_batchnorm
+        torch.manual_seed(11)
+        blk = S.BlockGen(2, _cfg()).cuda().train()
+        convert_sync_batchnorm(blk)
+        data = torch.load(os.path.join(out_dir, "data.pt"))
+        half = data["x"].shape[1] // world
+        x = data["x"][:, rank * half:(rank + 1) * half].cuda().requires_grad_()
+        g = data["g"][:, rank * half:(rank + 1) * half].cuda()
+        out, _ = blk(x)
+        (out * g).sum().backward()
+        torch.cuda.synchronize()
+        torch.save({"out": out.detach().cpu(), "gx": x.grad.cpu(),
+                    "gw": [p.grad.cpu() for p in blk.parameters()],
+                    "rm": blk.net[0][1].running_mean.cpu(), "rv": blk.net[0][1].running_var.cpu()},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_syncbn_two_ranks_equal_full_batch(tmp_path, hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import snn_for_object_detection_amd as S
+    torch.manual_seed(3)
+    T, B, H, W = 5, 4, 9, 11
+    x = (torch.rand(T, B, 2, H, W) < 0.3).float() * 2.0
+    g = torch.randn(T, B, 4, H, W)
+    torch.save({"x": x, "g": g}, tmp_path / "data.pt")
+    # single-process reference on the full batch
+    torch.manual_seed(11)
+    blk = S.BlockGen(2, _cfg()).cuda().train()
+    xf = x.cuda().requires_grad_()
+    out, _ = blk(xf)
+    (out * g.cuda()).sum().backward()
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    out2 = torch.cat([r[0]["out"], r[1]["out"]], dim=1)
+    gx2 = torch.cat([r[0]["gx"], r[1]["gx"]], dim=1)
+    assert torch.allclose(out2, out.detach().cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gx2, xf.grad.cpu(), rtol=1e-4, atol=1e-6)
+    for k, p in enumerate(blk.parameters()):
+        assert torch.allclose(r[0]["gw"][k] + r[1]["gw"][k], p.grad.cpu(), rtol=1e-4, atol=1e-6), k
+    bn = blk.net[0][1]
+    assert torch.allclose(r[0]["rm"], bn.running_mean.cpu(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(r[0]["rv"], bn.running_var.cpu(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(r[0]["rm"], r[1]["rm"])
