@@ -309,37 +309,52 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
     }
     const bool d_ok = (co0 + d_cq) < g.Cout;
 
-    auto decode = [&](int64_t p0, int slot) {
+    // Pixel decode (image, oy, ox) of the 32 pixels of a stage: lane t < 32 owns pixel p0 + t, decodes it ONCE
+    // with a division and then walks forward 32 pixels per stage with carries (no division in the loop).
+    int d_img = 0, d_oy = 0, d_ox = 0;
+    int64_t d_p = p_lo + tid;
+    if (tid < WB_K) {
+        int64_t pp = d_p < g.Mtot ? d_p : 0;
+        d_ox = (int)(pp % g.Wo);
+        int64_t t = pp / g.Wo;
+        d_oy = (int)(t % g.Ho);
+        d_img = (int)(t / g.Ho);
+    }
+    auto decode = [&](int slot) {  // publish the current stage's pixels, then advance to the next stage
         if (tid < WB_K) {
-            const int64_t p = p0 + tid;
-            int ok = p < p_hi ? 1 : 0;
-            int64_t pp = ok ? p : 0;
-            int ox = (int)(pp % g.Wo);
-            int64_t t = pp / g.Wo;
-            int oy = (int)(t % g.Ho);
-            int img = (int)(t / g.Ho);
-            Pinfo[slot][tid][0] = img * g.H * g.W;
-            Pinfo[slot][tid][1] = oy * g.stride - g.pad;
-            Pinfo[slot][tid][2] = ox * g.stride - g.pad;
-            Pinfo[slot][tid][3] = ok;
+            Pinfo[slot][tid][0] = d_img * g.H * g.W;
+            Pinfo[slot][tid][1] = d_oy * g.stride - g.pad;
+            Pinfo[slot][tid][2] = d_ox * g.stride - g.pad;
+            Pinfo[slot][tid][3] = d_p < p_hi ? 1 : 0;
+            d_p += WB_K;
+            d_ox += WB_K;
+            while (d_ox >= g.Wo) {
+                d_ox -= g.Wo;
+                if (++d_oy == g.Ho) {
+                    d_oy = 0;
+                    ++d_img;
+                }
+            }
         }
     };
 
     f32x4 rd[DJ], rx[XJ];
     auto load_tiles = [&](int64_t p0, int slot) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
             const int row = d_pr + DP * j;
             const int64_t p = p0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < p_hi) {
-                if (VEC) {
-                    if (d_ok) v = *reinterpret_cast<const f32x4*>(dy + p * g.lddy + co0 + d_cq);
-                } else {
+            const bool ok = p < p_hi;
+            const int64_t pc = ok ? p : p_lo;  // clamped address: always load, mask afterwards (no branch)
+            f32x4 v = zero;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok ? co0 + d_cq : 0));
+                v = (ok & d_ok) ? v : zero;
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co0 + d_cq + e < g.Cout) v[e] = dy[p * g.lddy + co0 + d_cq + e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (ok && co0 + d_cq + e < g.Cout) v[e] = dy[p * g.lddy + co0 + d_cq + e];
             }
             rd[j] = v;
         }
@@ -347,18 +362,20 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
         for (int j = 0; j < XJ; ++j) {
             const int row = x_pr + XP * j;
             const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
-            const bool ok = Pinfo[slot][row][3] != 0;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const bool pok = Pinfo[slot][row][3] != 0;
+            f32x4 v = zero;
             if (VEC) {
                 const int iy = y0 + x_kh[0], ix = x0 + x_kw[0];
-                if (ok && x_ok[0] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                    v = *reinterpret_cast<const f32x4*>(x + ((int64_t)ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[0]);
+                const bool ok = pok & x_ok[0] & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+                const int iyc = min(max(iy, 0), g.H - 1), ixc = min(max(ix, 0), g.W - 1);
+                v = *reinterpret_cast<const f32x4*>(x + (int64_t)(ibase + iyc * g.W + ixc) * g.ldx + x_ci[0]);
+                v = ok ? v : zero;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int iy = y0 + x_kh[e], ix = x0 + x_kw[e];
-                    if (ok && x_ok[e] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                        v[e] = x[((int64_t)ibase + (int64_t)iy * g.W + ix) * g.ldx + x_ci[e]];
+                    if (pok && x_ok[e] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                        v[e] = x[(int64_t)(ibase + iy * g.W + ix) * g.ldx + x_ci[e]];
                 }
             }
             rx[j] = v;
@@ -379,18 +396,18 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    decode(p_lo, 0);
+    decode(0);
     __syncthreads();
     load_tiles(p_lo, 0);
-    decode(p_lo + WB_K, 1);
+    decode(1);
     store_tiles();
     __syncthreads();
 
     int slot = 1;
 #pragma unroll 1
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += WB_K) {
-        load_tiles(p0 + WB_K, slot);        // rows past p_hi load zeros
-        decode(p0 + 2 * WB_K, slot ^ 1);    // slot^1 was last read one iteration ago, before a barrier
+        load_tiles(p0 + WB_K, slot);  // rows past p_hi load zeros
+        decode(slot ^ 1);             // pixels of stage p0 + 2*WB_K; slot^1 was last read before a barrier
 #pragma unroll
         for (int ks = 0; ks < WB_K / 2; ++ks) {
             float a[TM], b[TN];
