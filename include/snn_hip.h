@@ -92,6 +92,12 @@ int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, in
  *   in the epilogue (result = conv + addend); passing the destination itself accumulates in place.  This
  *   fuses the gradient sum of a tensor consumed by several branches (generator.py:181-187) into the dgrad.
  * wgrad accumulate != 0 : the result is added to dw instead of overwriting it. */
+/* Arithmetic of the BACKWARD convolutions (process-wide): 0 = exact fp32 MFMA; 1 (default) = "bf16 x 3":
+ * operands split into bf16 hi + lo, product = hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation,
+ * relative error ~2^-16 per product.  The forward convolution is always exact fp32. */
+int snn_set_backward_precision(int mode);
+int snn_get_backward_precision(void);
+
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                    int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);

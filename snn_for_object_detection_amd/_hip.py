@@ -33,6 +33,8 @@ SIGNATURES = {
     "snn_nchw_to_nhwc": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "snn_nhwc_to_nchw": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "snn_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "snn_set_backward_precision": (c_int, [_I]),
+    "snn_get_backward_precision": (c_int, []),
     "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

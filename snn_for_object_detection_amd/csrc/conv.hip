@@ -50,10 +50,19 @@ struct ConvGeom {
     unsigned magic_ic, magic_kw;
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS images: 80 B keeps ds_read_b128 conflict-free
+
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
 
-template <int BN, int WM, int WN, bool DGRAD, bool VEC>
+// SPLIT = false: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the forward / parity path.
+// SPLIT = true : "bf16 x 3": every fp32 operand is split on the way into LDS into hi = bf16(x) and
+//   lo = bf16(x - hi); the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+//   (relative error ~2^-16 per product instead of 2^-24, at 16/3 of the fp32 matrix rate).  Used for the
+//   data gradient only, where a 1e-5 relative error is far inside the gradient tolerance.
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add) {
@@ -61,8 +70,15 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    constexpr int A_BYTES = SPLIT ? 2 * BM * LDB * 2 : BM * LDK * 4;
+    constexpr int B_BYTES = SPLIT ? 2 * BN * LDB * 2 : BN * LDK * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = reinterpret_cast<float*>(smem + A_BYTES);
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);                 // [BM][LDB] high parts
+    __bf16* Al = Ah + BM * LDB;                                   // [BM][LDB] low parts
+    __bf16* Bh = reinterpret_cast<__bf16*>(smem + A_BYTES);
+    __bf16* Bl = Bh + BN * LDB;
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -163,11 +179,28 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
             }
         }
     };
+    auto split_store = [&](const f32x4& v, __bf16* hi_img, __bf16* lo_img, int row) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (__bf16)v[e];
+            lo[e] = (__bf16)(v[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<bf16x4*>(&hi_img[row * LDB + kq]) = hi;
+        *reinterpret_cast<bf16x4*>(&lo_img[row * LDB + kq]) = lo;
+    };
     auto store_tiles = [&]() {
+        if (SPLIT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[(lr + 32 * j) * LDK + kq]) = ra[j];
+            for (int j = 0; j < 4; ++j) split_store(ra[j], Ah, Al, lr + 32 * j);
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * j) * LDK + kq]) = rb[j];
+            for (int j = 0; j < BROWS; ++j) split_store(rb[j], Bh, Bl, lr + 32 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[(lr + 32 * j) * LDK + kq]) = ra[j];
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * j) * LDK + kq]) = rb[j];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -191,10 +224,36 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
         load_tiles(k0 + BK);
         // keep the prefetch ahead of the MFMA chain: its latency must be covered by the whole k-step
         __builtin_amdgcn_sched_barrier(0);
+        if (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
         const float* Ac = As;
         const float* Bc = Bs;
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
+        for (int ks = 0; ks < (SPLIT ? 0 : BK / 8); ++ks) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -453,7 +512,10 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DGRAD>
+// backward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 x 3 split products (snn_set_backward_precision)
+static int g_backward_split = 1;
+
+template <bool DGRAD, bool SPLIT>
 static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
                          int64_t ld_add, hipStream_t st, const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
@@ -463,10 +525,10 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     do {                                                                                                    \
         dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
         if (vec)                                                                                            \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true>), grid, dim3(kThreads), 0, st, in, \
-                               wk, out, g, addend, ld_add);                                                 \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT>), grid, dim3(kThreads), 0, st, \
+                               in, wk, out, g, addend, ld_add);                                             \
         else                                                                                                \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false>), grid, dim3(kThreads), 0, st,   \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, false>), grid, dim3(kThreads), 0, st, \
                                in, wk, out, g, addend, ld_add);                                             \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
@@ -493,6 +555,13 @@ static int check_conv_shape(const char* name, int64_t N, int H, int W, int Cin, 
 
 }  // namespace
 
+extern "C" int snn_set_backward_precision(int mode) {
+    SNN_REQUIRE(mode == 0 || mode == 1, "snn_set_backward_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+    g_backward_split = mode;
+    return 0;
+}
+extern "C" int snn_get_backward_precision(void) { return g_backward_split; }
+
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                               const float* addend, int64_t ld_addend, void* stream) {
@@ -511,7 +580,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
-    return launch_gather<false>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
+    return launch_gather<false, false>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
 extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
@@ -529,6 +598,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     g.KtotFull = KH * KW * Cout;
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
+    const bool split = g_backward_split != 0;
     // one launch per stride phase: each class multiplies only the taps that can reach it
     for (int ph = 0; ph < stride && ph < H; ++ph)
         for (int pw = 0; pw < stride && pw < W; ++pw) {
@@ -541,7 +611,10 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = launch_gather<true>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_dgrad");
+            int rc = split ? launch_gather<true, true>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
+                                                       "snn_conv2d_dgrad")
+                           : launch_gather<true, false>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
+                                                        "snn_conv2d_dgrad");
             if (rc) return rc;
         }
     return 0;
