@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
     }
     auto decode = [&](int slot) {  // publish the current stage's pixels, then advance to the next stage
         if (tid < WB_K) {
-            Pinfo[slot][tid][0] = d_img * g.H * g.W;
+            Pinfo[slot][tid][0] = d_p < p_hi ? d_img * g.H * g.W : 0;  // invalid pixels read (and discard) image 0
             Pinfo[slot][tid][1] = d_oy * g.stride - g.pad;
             Pinfo[slot][tid][2] = d_ox * g.stride - g.pad;
             Pinfo[slot][tid][3] = d_p < p_hi ? 1 : 0;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
             const int row = d_pr + DP * j;
             const int64_t p = p0 + row;
             const bool ok = p < p_hi;
-            const int64_t pc = ok ? p : p_lo;  // clamped address: always load, mask afterwards (no branch)
+            const int64_t pc = ok ? p : 0;  // clamped address: always load, mask afterwards (no branch)
             f32x4 v = zero;
             if (VEC) {
                 v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok ? co0 + d_cq : 0));
@@ -497,6 +497,203 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (co < g.Cout) slab[(int64_t)co * g.Ktot + kc] = acc[i][j][e];
+            }
+        }
+}
+
+// bf16 x 3 form of the weight gradient (see k_conv_gather<..., SPLIT>): both operands are split into bf16 hi / lo
+// on the way into LDS.  K = pixels must be contiguous per lane for the bf16 MFMA, so every loader thread takes FOUR
+// consecutive pixels of its 4-channel group, transposes the 4x4 block in registers and writes [column][pixel]
+// images (80-byte rows, conflict-free ds_read_b128 fragments).
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* __restrict__ x,
+                                                                                  const float* __restrict__ dy,
+                                                                                  float* __restrict__ ws, WgradGeom g) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
+    constexpr int DG = BMc / 4, XG = BNk / 4;                                  // 4-channel groups per pixel row
+    constexpr int DQ = (8 * DG + kThreads - 1) / kThreads, XQ = (8 * XG + kThreads - 1) / kThreads;  // quads / thread
+    __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDB];
+    __shared__ int Pinfo[2][WB_K][4];
+
+    const int tid = threadIdx.x;
+    const int lane_id = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane_id & 31, h = lane_id >> 5;
+
+    const int tiles = g.tiles_m * g.tiles_n;
+    int L = blockIdx.x, z, tile;
+    if (g.splitk % 8 == 0) {
+        z = (L % 8) + 8 * (L / (8 * tiles));
+        tile = (L / 8) % tiles;
+    } else {
+        z = L / tiles;
+        tile = L % tiles;
+    }
+    const int co0 = (tile % g.tiles_m) * BMc;
+    const int kc0 = (tile / g.tiles_m) * BNk;
+    const int64_t p_lo = (int64_t)z * g.pix_per_split;
+    int64_t p_hi = p_lo + g.pix_per_split;
+    if (p_hi > g.Mtot) p_hi = g.Mtot;
+
+    const int d_cq = (tid % DG) * 4, d_q0 = tid / DG;   // quad index of pass q: d_q0 + (kThreads / DG) * q
+    const int x_cq = (tid % XG) * 4, x_q0 = tid / XG;
+    const bool d_ok = (co0 + d_cq) < g.Cout;
+    const int kc = kc0 + x_cq;
+    const bool x_ok = kc < g.Ktot;
+    const int tap = (x_ok ? kc : 0) / g.Cin;
+    const int x_ci = (x_ok ? kc : 0) - tap * g.Cin;
+    const int x_kh = tap / g.KW, x_kw = tap - x_kh * g.KW;
+
+    int d_img = 0, d_oy = 0, d_ox = 0;
+    int64_t d_p = p_lo + tid;
+    if (tid < WB_K) {
+        int64_t pp = d_p < g.Mtot ? d_p : 0;
+        d_ox = (int)(pp % g.Wo);
+        int64_t t = pp / g.Wo;
+        d_oy = (int)(t % g.Ho);
+        d_img = (int)(t / g.Ho);
+    }
+    auto decode = [&](int slot) {
+        if (tid < WB_K) {
+            Pinfo[slot][tid][0] = d_p < p_hi ? d_img * g.H * g.W : 0;  // invalid pixels read (and discard) image 0
+            Pinfo[slot][tid][1] = d_oy * g.stride - g.pad;
+            Pinfo[slot][tid][2] = d_ox * g.stride - g.pad;
+            Pinfo[slot][tid][3] = d_p < p_hi ? 1 : 0;
+            d_p += WB_K;
+            d_ox += WB_K;
+            while (d_ox >= g.Wo) {
+                d_ox -= g.Wo;
+                if (++d_oy == g.Ho) {
+                    d_oy = 0;
+                    ++d_img;
+                }
+            }
+        }
+    };
+
+    f32x4 rd[DQ][4], rx[XQ][4];
+    auto load_tiles = [&](int64_t p0, int slot) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            const int quad = d_q0 + (kThreads / DG) * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t p = p0 + quad * 4 + e;
+                const bool ok = (quad < 8) & (p < p_hi) & d_ok;
+                const int64_t pc = ok ? p : 0;
+                f32x4 v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok ? co0 + d_cq : 0));
+                rd[q][e] = ok ? v : zero;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int quad = x_q0 + (kThreads / XG) * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = (quad < 8 ? quad : 0) * 4 + e;
+                const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
+                const bool pok = Pinfo[slot][row][3] != 0;
+                const int iy = y0 + x_kh, ix = x0 + x_kw;
+                const bool ok = (quad < 8) & pok & x_ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+                const int iyc = min(max(iy, 0), g.H - 1), ixc = min(max(ix, 0), g.W - 1);
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(ibase + iyc * g.W + ixc) * g.ldx + x_ci);
+                rx[q][e] = ok ? v : zero;
+            }
+        }
+    };
+    // 4 pixels x 4 channels -> per channel the 4 pixels as bf16 hi / lo, 8 bytes each
+    auto store_quad = [&](const f32x4 (&v)[4], __bf16* hi_img, __bf16* lo_img, int col0, int quad) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (__bf16)v[e][c];
+                lo[e] = (__bf16)(v[e][c] - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4*>(&hi_img[(col0 + c) * LDB + quad * 4]) = hi;
+            *reinterpret_cast<bf16x4*>(&lo_img[(col0 + c) * LDB + quad * 4]) = lo;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            const int quad = d_q0 + (kThreads / DG) * q;
+            if (quad < 8) store_quad(rd[q], Dh, Dl, d_cq, quad);
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int quad = x_q0 + (kThreads / XG) * q;
+            if (quad < 8) store_quad(rx[q], Xh, Xl, x_cq, quad);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    decode(0);
+    __syncthreads();
+    load_tiles(p_lo, 0);
+    decode(1);
+    store_tiles();
+    __syncthreads();
+
+    int slot = 1;
+#pragma unroll 1
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += WB_K) {
+        load_tiles(p0 + WB_K, slot);
+        decode(slot ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < WB_K / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        slot ^= 1;
+    }
+
+    float* slab = ws + (int64_t)z * g.Cout * (int64_t)g.Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int kcol = kc0 + (wn * TN + j) * 32 + r;
+            if (kcol >= g.Ktot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < g.Cout) slab[(int64_t)co * g.Ktot + kcol] = acc[i][j][e];
             }
         }
 }
@@ -648,8 +845,10 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     const int64_t Ktot = (int64_t)KH * KW * Cin;
     const WgradTile t = wgrad_tile(Cout, (int)Ktot);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
-    // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time)
-    int64_t s = ((int64_t)t.blocks_per_cu * SNN_NUM_CU) / tiles;
+    // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time);
+    // the bf16x3 variants of the three large tiles need > 168 registers: 2 blocks per CU
+    const int resident = (g_backward_split && t.id <= 2 && Cin % 4 == 0 && Cout % 4 == 0) ? 2 : t.blocks_per_cu;
+    int64_t s = ((int64_t)resident * SNN_NUM_CU) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
     if (s > max_by_work) s = max_by_work;
@@ -687,7 +886,10 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
+        if (vec && g_backward_split)                                                                           \
+            hipLaunchKernelGGL((k_conv_wgrad_split<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,   \
+                               workspace, g);                                                                  \
+        else if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
                                     dy, workspace, g);                                                         \
         else hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, false>), grid, dim3(kThreads), 0, st, x, dy, \
                                 workspace, g);                                                                 \
