@@ -23,6 +23,7 @@
 //
 // fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what the 1e-4
 // parity target against the CPU reference needs.
+#include <stdlib.h>
 #include "snn_common.h"
 
 namespace {
@@ -821,15 +822,21 @@ namespace {
 struct WgradTile { int bm, bn, id, blocks_per_cu; };
 // candidate block tiles (out-channels x (tap,ci) columns); pick the one that wastes the least MFMA work on
 // padding, larger tiles first on ties (fewer LDS / L2 bytes per FLOP)
-static WgradTile wgrad_tile(int Cout, int Ktot) {
+static WgradTile wgrad_tile(int Cout, int Ktot, bool split) {
     // blocks_per_cu: residency of each variant (registers / LDS), used to size the pixel split to ONE full wave
     static const WgradTile cand[] = {{128, 128, 0, 3}, {64, 256, 1, 3}, {32, 256, 2, 4},
                                      {128, 64, 3, 3},  {64, 64, 4, 3},  {32, 128, 5, 3}};
+    if (const char* force = getenv("SNN_WGRAD_TILE")) {  // tuning aid
+        int id = atoi(force);
+        if (id >= 0 && id < 6) return cand[id];
+    }
     WgradTile best = cand[0];
     double best_eff = -1.0;
     for (const WgradTile& c : cand) {
         double padded = (double)(snn_ceil_div(Cout, c.bm) * c.bm) * (double)(snn_ceil_div(Ktot, c.bn) * c.bn);
         double eff = (double)Cout * Ktot / padded;
+        // with the bf16x3 MFMAs (5x cheaper) the per-stage overhead dominates: favour the large tiles (measured)
+        if (split && c.id <= 1) eff *= 1.4;
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
             best = c;
@@ -843,11 +850,12 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
     const int64_t M = N * Ho * (int64_t)Wo;
     const int64_t Ktot = (int64_t)KH * KW * Cin;
-    const WgradTile t = wgrad_tile(Cout, (int)Ktot);
+    const bool split_mode = g_backward_split && Cin % 4 == 0 && Cout % 4 == 0;
+    const WgradTile t = wgrad_tile(Cout, (int)Ktot, split_mode);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
     // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time);
     // the bf16x3 variants of the three large tiles need > 168 registers: 2 blocks per CU
-    const int resident = (g_backward_split && t.id <= 2 && Cin % 4 == 0 && Cout % 4 == 0) ? 2 : t.blocks_per_cu;
+    const int resident = (split_mode && t.id <= 2) ? 2 : t.blocks_per_cu;
     int64_t s = ((int64_t)resident * SNN_NUM_CU) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
@@ -874,12 +882,12 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
     g.pix_per_split = snn_ceil_div(snn_ceil_div(g.Mtot, splitk), WB_K) * WB_K;
-    const WgradTile t = wgrad_tile(Cout, g.Ktot);
+    const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
+                     aligned16(dy);
+    const WgradTile t = wgrad_tile(Cout, g.Ktot, g_backward_split && Cin % 4 == 0 && Cout % 4 == 0);
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
     g.splitk = splitk;
-    const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
-                     aligned16(dy);
     const int64_t nblocks = (int64_t)g.tiles_m * g.tiles_n * splitk;
     SNN_REQUIRE(nblocks <= 0x7fffffff, "snn_conv2d_wgrad: grid too large");
     dim3 grid((unsigned)nblocks);
