@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
+    ap.add_argument("--backward-precision", choices=("bf16x3", "fp32"), default="bf16x3",
+                    help="arithmetic of the backward convolutions; the forward is always exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
@@ -120,6 +122,7 @@ def main():
     from snn_for_object_detection_amd.profiler import KernelProfiler
     from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters
     _hip.load()
+    S.functional.set_backward_precision(args.backward_precision)
 
     T, B, H, W = args.timesteps, args.batch, args.height, args.width
     torch.manual_seed(2)  # same reference init on every rank
@@ -224,6 +227,9 @@ def main():
                             "fwd + loss(last step) + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
                 "sync_batchnorm": bool(args.sync_bn and world > 1),
+                "arithmetic": "fp32 storage; forward conv exact fp32 MFMA; backward conv "
+                              + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, fp32 accumulate, rel 1e-5)"
+                                 if args.backward_precision == "bf16x3" else "exact fp32 MFMA"),
                 "loss": float(loss.item()),
             },
             "roofline": roofline,

@@ -31,6 +31,23 @@ def neuron_params(dt: float = DEFAULT_DT) -> NeuronParams:
                         1.0, torch.as_tensor(1.0 / 1e-3).item(), torch.as_tensor(1.0 / 5e-3).item(), dt, 0.0)
 
 
+# ------------------------------------------------------------------------------------------- precision
+def set_backward_precision(mode: str) -> None:
+    """Arithmetic of the backward convolutions (data / weight gradients).
+
+    ``"bf16x3"`` (default): fp32 operands are split into bf16 hi + lo and multiplied as hi*hi + hi*lo + lo*hi on
+    the bf16 matrix cores with fp32 accumulation - relative error ~1e-5 of the exact product, 2-2.5x faster on
+    MFMA-bound shapes.  ``"fp32"``: exact fp32 MFMA (an fmaf chain), as the forward convolution always is."""
+    modes = {"fp32": 0, "bf16x3": 1}
+    if mode not in modes:
+        raise ValueError(f"backward precision must be one of {sorted(modes)}")
+    _hip.call("snn_set_backward_precision", modes[mode])
+
+
+def get_backward_precision() -> str:
+    return ("fp32", "bf16x3")[_hip.query("snn_get_backward_precision")]
+
+
 # ------------------------------------------------------------------------------------------- helpers
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream

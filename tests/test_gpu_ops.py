@@ -311,3 +311,29 @@ def test_errors_surface_as_exceptions(HF):
         BlockGen(4, Residual([[Conv(8, 1)], [Conv(6, 1)]]))
     with pytest.raises(RuntimeError, match="channels"):
         HF.conv2d(torch.zeros(1, 2, 4, 4).cuda(), torch.zeros(3, 5, 3, 3).cuda(), 1, 1)
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-6), ("bf16x3", 3e-5)])
+def test_backward_precision_modes_against_fp64(HF, mode, tol):
+    """Gradient accuracy of the two backward arithmetics against an fp64 reference (forward is always fp32)."""
+    torch.manual_seed(12)
+    T, B, Cin, H, W, Cout, k, s = 2, 2, 64, 20, 24, 128, 3, 1
+    x = torch.randn(T, B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv2d(xr.flatten(0, 1), wr, stride=s, padding=1)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    prev = HF.get_backward_precision()
+    try:
+        HF.set_backward_precision(mode)
+        assert HF.get_backward_precision() == mode
+        xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
+        yd = HF.conv2d(xd, wd, stride=s, padding=1)
+        yd.backward(gy.float().view(yd.shape).cuda())
+        assert rel_err(yd.flatten(0, 1), yr) < 2e-6          # forward: exact fp32 MFMA in both modes
+        assert rel_err(xd.grad, xr.grad) < tol and rel_err(wd.grad, wr.grad) < tol
+    finally:
+        HF.set_backward_precision(prev)
+    with pytest.raises(ValueError):
+        HF.set_backward_precision("fp8")
