@@ -89,8 +89,10 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
+    ap.add_argument("--forward-precision", choices=("bf16x6", "fp32"), default="bf16x6",
+                    help="forward conv arithmetic: bf16x6 = 3-way bf16 split, 6 products, fp32-grade accuracy")
     ap.add_argument("--backward-precision", choices=("bf16x3", "fp32"), default="bf16x3",
-                    help="arithmetic of the backward convolutions; the forward is always exact fp32 MFMA")
+                    help="arithmetic of the backward convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
@@ -122,6 +124,7 @@ def main():
     from snn_for_object_detection_amd.profiler import KernelProfiler
     from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters
     _hip.load()
+    S.functional.set_forward_precision(args.forward_precision)
     S.functional.set_backward_precision(args.backward_precision)
 
     T, B, H, W = args.timesteps, args.batch, args.height, args.width
@@ -227,8 +230,12 @@ def main():
                             "fwd + loss(last step) + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
                 "sync_batchnorm": bool(args.sync_bn and world > 1),
-                "arithmetic": "fp32 storage; forward conv exact fp32 MFMA; backward conv "
-                              + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, fp32 accumulate, rel 1e-5)"
+                "arithmetic": "fp32 storage and accumulation; forward conv "
+                              + ("bf16x6 split products (3-way bf16 split of both operands, fp32-grade: rel 5e-7 vs "
+                                 "fp64, same as the fp32 MFMA)" if args.forward_precision == "bf16x6"
+                                 else "exact fp32 MFMA")
+                              + "; backward conv "
+                              + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, rel 1e-5)"
                                  if args.backward_precision == "bf16x3" else "exact fp32 MFMA"),
                 "loss": float(loss.item()),
             },

@@ -94,9 +94,14 @@ int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, in
  * wgrad accumulate != 0 : the result is added to dw instead of overwriting it. */
 /* Arithmetic of the BACKWARD convolutions (process-wide): 0 = exact fp32 MFMA; 1 (default) = "bf16 x 3":
  * operands split into bf16 hi + lo, product = hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation,
- * relative error ~2^-16 per product.  The forward convolution is always exact fp32. */
+ * relative error ~2^-16 per product. */
 int snn_set_backward_precision(int mode);
 int snn_get_backward_precision(void);
+/* Arithmetic of the FORWARD convolution: 3 (default) = "bf16 x 6": three-way bf16 split of both operands
+ * (h + m + l = all 24 significant bits) and the six leading products with fp32 accumulation - fp32-grade accuracy
+ * (dropped terms 2^-25; measured relative error vs fp64 equal to the fp32 MFMA's); 0 = exact fp32 MFMA (fmaf chain). */
+int snn_set_forward_precision(int mode);
+int snn_get_forward_precision(void);
 
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,

@@ -35,6 +35,8 @@ SIGNATURES = {
     "snn_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "snn_set_backward_precision": (c_int, [_I]),
     "snn_get_backward_precision": (c_int, []),
+    "snn_set_forward_precision": (c_int, [_I]),
+    "snn_get_forward_precision": (c_int, []),
     "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
@@ -86,6 +88,13 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.snn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnn_hip.so ABI {lib.snn_abi_version()} != binding {ABI_VERSION}: rebuild")
+    # optional process-wide arithmetic overrides (defaults: forward exact fp32, backward bf16x3)
+    fwd = os.environ.get("SNN_FORWARD_PRECISION")
+    if fwd:
+        lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3}[fwd])
+    bwd = os.environ.get("SNN_BACKWARD_PRECISION")
+    if bwd:
+        lib.snn_set_backward_precision({"fp32": 0, "bf16x3": 1}[bwd])
     _lib = lib
     return lib
 

@@ -58,12 +58,15 @@ constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS image
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
 
-// SPLIT = false: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the forward / parity path.
-// SPLIT = true : "bf16 x 3": every fp32 operand is split on the way into LDS into hi = bf16(x) and
+// SPLIT = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32): an fmaf chain, the reference arithmetic.
+// SPLIT = 2: "bf16 x 3": every fp32 operand is split on the way into LDS into hi = bf16(x) and
 //   lo = bf16(x - hi); the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
-//   (relative error ~2^-16 per product instead of 2^-24, at 16/3 of the fp32 matrix rate).  Used for the
-//   data gradient only, where a 1e-5 relative error is far inside the gradient tolerance.
-template <int BN, int WM, int WN, bool DGRAD, bool VEC, bool SPLIT>
+//   (relative error ~2^-16 per product instead of 2^-24, at 16/3 of the fp32 matrix rate).  Default for the
+//   data gradient, where a 1e-5 relative error is far inside the gradient tolerance.
+// SPLIT = 3: "bf16 x 6": three-way split x = h + m + l (24 significant bits, i.e. the fp32 value itself) and the
+//   six products hh + hm + mh + mm + hl + lh; the dropped terms are 2^-25 relative - fp32-grade accuracy at
+//   16/6 of the fp32 matrix rate.
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT>
 __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add) {
@@ -71,15 +74,17 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int A_BYTES = SPLIT ? 2 * BM * LDB * 2 : BM * LDK * 4;
-    constexpr int B_BYTES = SPLIT ? 2 * BN * LDB * 2 : BN * LDK * 4;
+    constexpr int A_BYTES = SPLIT ? SPLIT * BM * LDB * 2 : BM * LDK * 4;
+    constexpr int B_BYTES = SPLIT ? SPLIT * BN * LDB * 2 : BN * LDK * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = reinterpret_cast<float*>(smem + A_BYTES);
     __bf16* Ah = reinterpret_cast<__bf16*>(smem);                 // [BM][LDB] high parts
     __bf16* Al = Ah + BM * LDB;                                   // [BM][LDB] low parts
+    __bf16* Am = Al + BM * LDB;                                   // [BM][LDB] middle parts (SPLIT == 3)
     __bf16* Bh = reinterpret_cast<__bf16*>(smem + A_BYTES);
     __bf16* Bl = Bh + BN * LDB;
+    __bf16* Bm = Bl + BN * LDB;
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -180,22 +185,28 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
             }
         }
     };
-    auto split_store = [&](const f32x4& v, __bf16* hi_img, __bf16* lo_img, int row) {
-        bf16x4 hi, lo;
+    auto split_store = [&](const f32x4& v, __bf16* hi_img, __bf16* mid_img, __bf16* lo_img, int row) {
+        bf16x4 hi, mid, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             hi[e] = (__bf16)v[e];
-            lo[e] = (__bf16)(v[e] - (float)hi[e]);
+            float rest = v[e] - (float)hi[e];
+            if (SPLIT == 3) {
+                mid[e] = (__bf16)rest;
+                rest = rest - (float)mid[e];
+            }
+            lo[e] = (__bf16)rest;
         }
         *reinterpret_cast<bf16x4*>(&hi_img[row * LDB + kq]) = hi;
+        if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&mid_img[row * LDB + kq]) = mid;
         *reinterpret_cast<bf16x4*>(&lo_img[row * LDB + kq]) = lo;
     };
     auto store_tiles = [&]() {
         if (SPLIT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_store(ra[j], Ah, Al, lr + 32 * j);
+            for (int j = 0; j < 4; ++j) split_store(ra[j], Ah, Am, Al, lr + 32 * j);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) split_store(rb[j], Bh, Bl, lr + 32 * j);
+            for (int j = 0; j < BROWS; ++j) split_store(rb[j], Bh, Bm, Bl, lr + 32 * j);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&As[(lr + 32 * j) * LDK + kq]) = ra[j];
@@ -228,25 +239,32 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
         if (SPLIT) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
                     ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
                     al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                    if (SPLIT == 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
                     bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
                     bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
+                    if (SPLIT == 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
+                    for (int j = 0; j < TN; ++j) {  // small terms first
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        if (SPLIT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
@@ -712,8 +730,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // backward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 x 3 split products (snn_set_backward_precision)
 static int g_backward_split = 1;
+// forward arithmetic: 3 = bf16 x 6 (default; fp32-grade, measured 5e-7 vs fp64 like the fp32 MFMA), 0 = exact fp32 MFMA
+static int g_forward_split = 3;
 
-template <bool DGRAD, bool SPLIT>
+template <bool DGRAD, int SPLIT>
 static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
                          int64_t ld_add, hipStream_t st, const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
@@ -726,7 +746,7 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT>), grid, dim3(kThreads), 0, st, \
                                in, wk, out, g, addend, ld_add);                                             \
         else                                                                                                \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, false>), grid, dim3(kThreads), 0, st, \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0>), grid, dim3(kThreads), 0, st, \
                                in, wk, out, g, addend, ld_add);                                             \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
@@ -759,6 +779,12 @@ extern "C" int snn_set_backward_precision(int mode) {
     return 0;
 }
 extern "C" int snn_get_backward_precision(void) { return g_backward_split; }
+extern "C" int snn_set_forward_precision(int mode) {
+    SNN_REQUIRE(mode == 0 || mode == 3, "snn_set_forward_precision: mode must be 0 (fp32) or 3 (bf16x6)");
+    g_forward_split = mode;
+    return 0;
+}
+extern "C" int snn_get_forward_precision(void) { return g_forward_split; }
 
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
@@ -778,7 +804,9 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
-    return launch_gather<false, false>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
+    if (g_forward_split == 3)
+        return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
+    return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
 extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
@@ -809,10 +837,10 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = split ? launch_gather<true, true>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
-                                                       "snn_conv2d_dgrad")
-                           : launch_gather<true, false>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
-                                                        "snn_conv2d_dgrad");
+            int rc = split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
+                                                    "snn_conv2d_dgrad")
+                           : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
+                                                    "snn_conv2d_dgrad");
             if (rc) return rc;
         }
     return 0;

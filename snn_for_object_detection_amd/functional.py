@@ -37,7 +37,7 @@ def set_backward_precision(mode: str) -> None:
 
     ``"bf16x3"`` (default): fp32 operands are split into bf16 hi + lo and multiplied as hi*hi + hi*lo + lo*hi on
     the bf16 matrix cores with fp32 accumulation - relative error ~1e-5 of the exact product, 2-2.5x faster on
-    MFMA-bound shapes.  ``"fp32"``: exact fp32 MFMA (an fmaf chain), as the forward convolution always is."""
+    MFMA-bound shapes.  ``"fp32"``: exact fp32 MFMA (an fmaf chain)."""
     modes = {"fp32": 0, "bf16x3": 1}
     if mode not in modes:
         raise ValueError(f"backward precision must be one of {sorted(modes)}")
@@ -46,6 +46,20 @@ def set_backward_precision(mode: str) -> None:
 
 def get_backward_precision() -> str:
     return ("fp32", "bf16x3")[_hip.query("snn_get_backward_precision")]
+
+
+def set_forward_precision(mode: str) -> None:
+    """Forward convolution arithmetic: ``"bf16x6"`` (default: three-way bf16 split of both operands = all 24
+    significant bits, six products, fp32 accumulation; fp32-grade accuracy at 16/6 of the fp32 MFMA rate) or
+    ``"fp32"`` (exact fp32 MFMA, an fmaf chain)."""
+    modes = {"fp32": 0, "bf16x6": 3}
+    if mode not in modes:
+        raise ValueError(f"forward precision must be one of {sorted(modes)}")
+    _hip.call("snn_set_forward_precision", modes[mode])
+
+
+def get_forward_precision() -> str:
+    return {0: "fp32", 3: "bf16x6"}[_hip.query("snn_get_forward_precision")]
 
 
 # ------------------------------------------------------------------------------------------- helpers

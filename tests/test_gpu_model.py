@@ -21,8 +21,19 @@ def S(hip_lib):
     return pkg
 
 
-def test_tiny_yolo_train_step_matches_oracle(S):
+@pytest.mark.parametrize("fwd,bwd", [("bf16x6", "bf16x3"), ("fp32", "fp32")], ids=["default-arith", "exact-fp32"])
+def test_tiny_yolo_train_step_matches_oracle(S, fwd, bwd):
     T, B, H, W = 4, 2, 32, 48
+    S.functional.set_forward_precision(fwd)
+    S.functional.set_backward_precision(bwd)
+    try:
+        _train_step_vs_oracle(S, T, B, H, W)
+    finally:
+        S.functional.set_forward_precision("bf16x6")
+        S.functional.set_backward_precision("bf16x3")
+
+
+def _train_step_vs_oracle(S, T, B, H, W):
     product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
     X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B)
     product.train()

@@ -331,9 +331,29 @@ def test_backward_precision_modes_against_fp64(HF, mode, tol):
         xd, wd = x.cuda().requires_grad_(), w.cuda().requires_grad_()
         yd = HF.conv2d(xd, wd, stride=s, padding=1)
         yd.backward(gy.float().view(yd.shape).cuda())
-        assert rel_err(yd.flatten(0, 1), yr) < 2e-6          # forward: exact fp32 MFMA in both modes
+        assert rel_err(yd.flatten(0, 1), yr) < 2e-6          # forward: fp32-grade in every mode
         assert rel_err(xd.grad, xr.grad) < tol and rel_err(wd.grad, wr.grad) < tol
     finally:
         HF.set_backward_precision(prev)
     with pytest.raises(ValueError):
         HF.set_backward_precision("fp8")
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+def test_forward_precision_modes_against_fp64(HF, mode):
+    """Both forward arithmetics are fp32-grade: the 3-way bf16 split (6 products) carries all 24 significant bits."""
+    torch.manual_seed(13)
+    prev = HF.get_forward_precision()
+    try:
+        HF.set_forward_precision(mode)
+        assert HF.get_forward_precision() == mode
+        for (Cin, Cout, k, s, H, W) in [(64, 128, 3, 1, 20, 24), (96, 64, 1, 1, 17, 19), (32, 32, 3, 2, 31, 30)]:
+            x = torch.randn(3, 2, Cin, H, W) * 3.0
+            w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+            ref = F.conv2d(x.double().flatten(0, 1), w.double(), stride=s, padding=k // 2)
+            y = HF.conv2d(x.cuda(), w.cuda(), stride=s, padding=k // 2)
+            assert rel_err(y.flatten(0, 1), ref) < 1.5e-6
+    finally:
+        HF.set_forward_precision(prev)
+    with pytest.raises(ValueError):
+        HF.set_forward_precision("bf16")
