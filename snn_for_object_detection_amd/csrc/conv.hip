@@ -49,6 +49,7 @@ struct ConvGeom {
     int ph, pw, kh0, kw0, nkh, nkw, OHc, OWc;
     // ceil(2^32 / d) for d = IC and d = (DGRAD ? nkw : KW): q = umulhi(n, magic) == n / d for n * d < 2^32
     unsigned magic_ic, magic_kw;
+    int out_vec;  // output (and addend) rows may be stored 16 bytes per lane
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -293,31 +294,51 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
+    // lane holds ONE channel of 16 pixels.  Each wave transposes its accumulators through LDS (the operand tiles
+    // are dead by now) so that a lane stores 16 contiguous bytes and a pixel row goes out as TN*128-byte runs:
+    // 4x fewer, wider store instructions (the k-short 1x1 convolutions are store-issue bound otherwise).
+    constexpr int EW = TN * 32 + 4;   // staged row length in floats
+    constexpr int LPR = TN * 8;       // lanes per staged row (4 floats each)
+    constexpr int RPP = 64 / LPR;     // rows per pass
+    static_assert(4 * 32 * EW * 4 <= A_BYTES + B_BYTES, "epilogue staging does not fit the operand tiles");
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
+    const bool ovec = g.out_vec != 0;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + r;
-            if (n >= g.OC) continue;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.Mtot) {
-                    int64_t pix = m;
-                    if (DGRAD && g.stride > 1) {
-                        int b = (int)(m % g.OWc);
-                        int64_t t = m / g.OWc;
-                        int a = (int)(t % g.OHc);
-                        int64_t img = t / g.OHc;
-                        pix = (img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
-                    }
-                    float v = acc[i][j][e];
-                    if (addend) v += addend[pix * ld_add + n];  // fused gradient accumulation (may alias out)
-                    out[pix * g.ldo + n] = v;
-                }
+            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+            const int row = pass * RPP + lane_id / LPR;
+            const int c4 = (lane_id % LPR) * 4;
+            const int64_t m = m0 + (wm * TM + i) * 32 + row;
+            const int n = n0 + wn * TN * 32 + c4;
+            if (m >= g.Mtot || n >= g.OC) continue;
+            int64_t pix = m;
+            if (DGRAD && g.stride > 1) {
+                int b = (int)(m % g.OWc);
+                int64_t t = m / g.OWc;
+                int a = (int)(t % g.OHc);
+                int64_t img = t / g.OHc;
+                pix = (img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
+            }
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
+            float* dst = out + pix * g.ldo + n;
+            if (ovec && n + 3 < g.OC) {
+                if (addend) v += *reinterpret_cast<const f32x4*>(addend + pix * ld_add + n);  // fused accumulation
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < g.OC) dst[q] = addend ? v[q] + addend[pix * ld_add + n + q] : v[q];
             }
         }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -739,15 +760,17 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(gm <= 0x7fffffff, "%s: too many pixels", name);
+    ConvGeom gg = g;
+    gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend)));
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
     do {                                                                                                    \
         dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
         if (vec)                                                                                            \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT>), grid, dim3(kThreads), 0, st, \
-                               in, wk, out, g, addend, ld_add);                                             \
+                               in, wk, out, gg, addend, ld_add);                                            \
         else                                                                                                \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0>), grid, dim3(kThreads), 0, st, \
-                               in, wk, out, g, addend, ld_add);                                             \
+                               in, wk, out, gg, addend, ld_add);                                            \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
     else if (g.OC <= 64) SNN_CONV_LAUNCH(64, 2, 2);
