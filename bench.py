@@ -29,7 +29,20 @@ sys.path.insert(0, ROOT)
 
 GEN1_H, GEN1_W = 240, 304
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+
+
+def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
+    """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3) or 6 (bf16x6) dense
+    bf16 MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
+    backward = kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
+    prec = bwd_prec if backward else fwd_prec
+    if prec == "bf16x3":
+        return PEAK_BF16_MATRIX_TFLOPS / 3.0, "bf16 dense MFMA / 3 products"
+    if prec == "bf16x6":
+        return PEAK_BF16_MATRIX_TFLOPS / 6.0, "bf16 dense MFMA / 6 products"
+    return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA"
 
 
 def synthetic_batch(T, B, H, W, num_classes, device, seed):
@@ -190,9 +203,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath) and (T, B, H, W) == (32, 5, GEN1_H, GEN1_W):
             traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+        peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
         roofline = {
-            "bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS,
-            "unit": "TFLOP/s", "frac": row["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+            "bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
+            "unit": "TFLOP/s", "frac": row["tflops"] / peak, "traffic": traffic,
+            "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
             "avg_launch_us": row["avg_us"], "launches_per_step": row["calls"] // 2,
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],

@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnn_hip.so")
+LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # SNN_HIP_LIB: tuning aid (ablation builds)
 
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2

@@ -26,6 +26,21 @@
 #include <stdlib.h>
 #include "snn_common.h"
 
+#ifdef SNN_STAMP
+// tuning aid (scratch builds only): per-phase cycle totals of wave 0 of the first 2048 blocks of the pipelined loop
+__device__ unsigned long long g_stamps[2048 * 8];
+__device__ unsigned long long g_stamps2[2048 * 4];
+extern "C" int snn_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int snn_debug_stamps2(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * n);
+}
+#define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -50,10 +65,14 @@ struct ConvGeom {
     // ceil(2^32 / d) for d = IC and d = (DGRAD ? nkw : KW): q = umulhi(n, magic) == n / d for n * d < 2^32
     unsigned magic_ic, magic_kw;
     int out_vec;  // output (and addend) rows may be stored 16 bytes per lane
+    int nimg;     // images in the gathered tensor (FAST loader: extent of its buffer resource)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS images: 80 B keeps ds_read_b128 conflict-free
 
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
@@ -67,8 +86,13 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // SPLIT = 3: "bf16 x 6": three-way split x = h + m + l (24 significant bits, i.e. the fp32 value itself) and the
 //   six products hh + hm + mh + mm + hl + lh; the dropped terms are 2^-25 relative - fp32-grade accuracy at
 //   16/6 of the fp32 matrix rate.
-template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT>
-__global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
+// FAST (host-checked: VEC, IC % 32 == 0, <= 31 taps, 4 images of the gathered tensor < 2 GiB): a k-step of 32 lies
+// inside ONE filter tap, so the tap decode is scalar (SALU) and a row's address is "row offset + scalar tap
+// offset".  Loads are raw buffer loads relative to the block's first image; padding / out-of-range rows get the
+// offset 0xFFFFFFFF and the hardware range check returns zeros - no clamps, no value selects, no 64-bit address
+// arithmetic in the loop (the generic loader spends more VALU cycles on addresses than the MFMAs take).
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST>
+__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add) {
     constexpr int TM = BM / WM / 32;
@@ -88,6 +112,9 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     __bf16* Bm = Bl + BN * LDB;
 
     const int tid = threadIdx.x;
+#ifdef SNN_STAMP
+    const unsigned long long st_kernel_begin = __builtin_readcyclecounter();
+#endif
     const int lane_id = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane_id & 31, h = lane_id >> 5;
@@ -96,27 +123,36 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     const int n0 = blockIdx.y * BN;
 
     // ---- per-thread loader geometry: rows lr + 32*j, k offset kq
-    const int lr = tid >> 3, kq = (tid & 7) * 4;
+    // Rows are permuted so that the two rows written by one 16-lane LDS store group lie 4 rows (320 B) apart: with
+    // the 80-byte row pitch adjacent rows would overlap by 4 banks (measured: a third of all LDS cycles were
+    // bank conflicts); 16 dwords apart modulo 32 banks they tile the banks exactly.
+    const int lrr = tid >> 3;
+    const int lr = ((lrr >> 1) & 3) + 4 * (lrr & 1) + 8 * (lrr >> 3), kq = (tid & 7) * 4;
     int a_y0[4], a_x0[4];
     int a_base[4];  // first pixel of the image (the host checks img * IH * IW < 2^31)
     bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int64_t m = m0 + lr + 32 * j;
-        a_ok[j] = m < g.Mtot;
-        int64_t mm = a_ok[j] ? m : 0;
-        const int ow_ = DGRAD ? g.OWc : g.OW, oh_ = DGRAD ? g.OHc : g.OH;
-        int ox = (int)(mm % ow_);
-        int64_t t = mm / ow_;
-        int oy = (int)(t % oh_);
-        int64_t img = t / oh_;
-        a_base[j] = (int)(img * g.IH * (int64_t)g.IW);
+        // 32-bit arithmetic (the host checks Mtot < 2^31): a 64-bit division costs ~10x a 32-bit one, and the
+        // 13 of them per thread made the prologue 14 % of a block's lifetime (measured with s_memtime stamps)
+        const unsigned m = (unsigned)m0 + lr + 32 * j;
+        a_ok[j] = m < (unsigned)g.Mtot;
+        const unsigned mm = a_ok[j] ? m : 0u;
+        const unsigned ow_ = DGRAD ? g.OWc : g.OW, oh_ = DGRAD ? g.OHc : g.OH;
+        const unsigned t = mm / ow_;
+        const int ox = (int)(mm - t * ow_);
+        const unsigned img = t / oh_;
+        const int oy = (int)(t - img * oh_);
+        a_base[j] = (int)(img * (unsigned)(g.IH * g.IW));
         if (!DGRAD) {
             a_y0[j] = oy * g.stride - g.pad;
             a_x0[j] = ox * g.stride - g.pad;
+        } else if (g.stride == 1) {
+            a_y0[j] = oy + g.pad;  // stride 1: ph = pw = kh0 = kw0 = 0
+            a_x0[j] = ox + g.pad;
         } else {
-            a_y0[j] = (oy * g.stride + g.ph + g.pad - g.kh0) / g.stride;
-            a_x0[j] = (ox * g.stride + g.pw + g.pad - g.kw0) / g.stride;
+            a_y0[j] = (int)((unsigned)(oy * g.stride + g.ph + g.pad - g.kh0) / (unsigned)g.stride);
+            a_x0[j] = (int)((unsigned)(ox * g.stride + g.pw + g.pad - g.kw0) / (unsigned)g.stride);
         }
     }
 
@@ -139,7 +175,85 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 
     f32x4 ra[4], rb[BROWS];
 
+    // ---- FAST loader state
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    int a_rel[4];            // byte offset of (row pixel origin, channel kq) from the block's first image
+    unsigned a_mask[4];      // bit t: tap t of this row reads inside the image
+    unsigned b_rel[BROWS];   // byte offset of (weight row, column kq); >= 2^31 for rows past OC
+    if (FAST) {
+        const int ow_ = DGRAD ? g.OWc : g.OW, oh_ = DGRAD ? g.OHc : g.OH;
+        const int64_t img0 = (unsigned)m0 / (unsigned)(oh_ * ow_);
+        const int64_t ipix = (int64_t)g.IH * g.IW;
+        const int64_t bytes = ((((int64_t)g.nimg - img0) * ipix - 1) * g.ldi + g.IC) * 4;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + img0 * ipix * g.ldi), 0,
+                                                 bytes > 0xffffffffLL ? (int)0xffffffffu : (int)(unsigned)bytes,
+                                                 0x00020000);
+        rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, g.OC * g.KtotFull * 4, 0x00020000);
+        const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
+        const int tw_n = DGRAD ? g.nkw : g.KW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int relpix = (a_base[j] - (int)(img0 * ipix)) + a_y0[j] * g.IW + a_x0[j];
+            a_rel[j] = (relpix * (int)g.ldi + kq) * 4;
+            unsigned mask = 0;
+            for (int th = 0, t = 0; th < (DGRAD ? g.nkh : g.KH); ++th)
+                for (int tw = 0; tw < tw_n; ++tw, ++t) {
+                    const int iy = DGRAD ? a_y0[j] - th : a_y0[j] + th, ix = DGRAD ? a_x0[j] - tw : a_x0[j] + tw;
+                    if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << t;
+                }
+            a_mask[j] = a_ok[j] ? mask : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int n = n0 + lr + 32 * j;
+            b_rel[j] = n < g.OC ? (unsigned)(n * g.KtotFull + kq) * 4u : 0x80000000u;
+        }
+    }
+    const unsigned fast_tw_n = DGRAD ? g.nkw : g.KW;
+    const unsigned fast_tw_one = fast_tw_n == 1 ? 1u : 0u;  // magic_u32(1) is 0: q = umulhi(n, 0) + n
+    auto load_tiles_fast = [&](int k0n) {  // k0n is block-uniform: everything up to the per-row adds is scalar
+        const bool kin = k0n < g.Ktot;
+        const int tap = (int)__umulhi((unsigned)k0n, g.magic_ic);  // IC >= 32 here
+        const int c0 = k0n - tap * g.IC;
+        const int th = (int)(__umulhi((unsigned)tap, g.magic_kw) + (unsigned)tap * fast_tw_one);
+        const int tw = tap - th * (int)fast_tw_n;
+        int toff, wcol0;
+        if (!DGRAD) {
+            toff = ((th * g.IW + tw) * (int)g.ldi + c0) * 4;
+            wcol0 = k0n;
+        } else {
+            toff = (c0 - (th * g.IW + tw) * (int)g.ldi) * 4;
+            wcol0 = ((g.kh0 + g.stride * th) * g.KW + (g.kw0 + g.stride * tw)) * g.IC + c0;
+        }
+        const int tbit = kin ? tap : 31;  // bit 31 is never set: a prefetch past the last k-step loads zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int voff = ((a_mask[j] >> tbit) & 1u) ? a_rel[j] + toff : -1;
+#if defined(SNN_ABL_NOLOAD)
+            ra[j] = f32x4{(float)voff, (float)k0n, 1.f, 2.f};
+#elif defined(SNN_ABL_HOT)
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (voff & 0x3ff0), 0, 0));
+#else
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
+#endif
+        }
+        const unsigned wb = (unsigned)wcol0 * 4u;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+#if defined(SNN_ABL_NOLOAD)
+            rb[j] = f32x4{(float)(b_rel[j] + wb), 1.f, 2.f, 3.f};
+#elif defined(SNN_ABL_HOT)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)((b_rel[j] + wb) & 0x3ff0), 0, 0));
+#else
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(b_rel[j] + wb), 0, 0));
+#endif
+    };
+
     auto load_tiles = [&](int k0) {
+        if (FAST) {
+            load_tiles_fast(k0);
+            return;
+        }
         const int kk = k0 + kq;
         if (VEC) {
             // Branch-free: every lane always loads from a clamped (valid) address and masks the value afterwards,
@@ -189,14 +303,22 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
     auto split_store = [&](const f32x4& v, __bf16* hi_img, __bf16* mid_img, __bf16* lo_img, int row) {
         bf16x4 hi, mid, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = (__bf16)v[e];
-            float rest = v[e] - (float)hi[e];
+        for (int e = 0; e < 4; e += 2) {  // two elements per v_cvt_pk_bf16_f32; widening back is a shift / mask
+            f32x2 rest = {v[e], v[e + 1]};
+            bf16x2 p = __builtin_convertvector(rest, bf16x2);
+            unsigned bits = __builtin_bit_cast(unsigned, p);
+            hi[e] = p[0]; hi[e + 1] = p[1];
+            rest[0] -= __builtin_bit_cast(float, bits << 16);
+            rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
             if (SPLIT == 3) {
-                mid[e] = (__bf16)rest;
-                rest = rest - (float)mid[e];
+                p = __builtin_convertvector(rest, bf16x2);
+                bits = __builtin_bit_cast(unsigned, p);
+                mid[e] = p[0]; mid[e + 1] = p[1];
+                rest[0] -= __builtin_bit_cast(float, bits << 16);
+                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
             }
-            lo[e] = (__bf16)rest;
+            p = __builtin_convertvector(rest, bf16x2);
+            lo[e] = p[0]; lo[e + 1] = p[1];
         }
         *reinterpret_cast<bf16x4*>(&hi_img[row * LDB + kq]) = hi;
         if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&mid_img[row * LDB + kq]) = mid;
@@ -224,74 +346,211 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (g.Ktot > 0) {  // a dgrad stride-phase class may have no tap at all: its pixels are plain zeros
-        load_tiles(0);
-        store_tiles();
-    }
-    __syncthreads();
-
-    // Branch-free steady state (a tile past Ktot loads zeros and is never read): keeping the MFMA chain in
-    // one basic block lets the accumulators stay in their registers across iterations.
-#pragma unroll 1
-    for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
-        load_tiles(k0 + BK);
-        // keep the prefetch ahead of the MFMA chain: its latency must be covered by the whole k-step
-        __builtin_amdgcn_sched_barrier(0);
-        if (SPLIT) {
+    if constexpr (FAST && SPLIT != 0) {
+        // ---- software-pipelined main loop (2 waves / SIMD).  While the MFMAs of tile k run from LDS, the SAME wave
+        // converts tile k+1 (raw fp32 in registers since the previous k-step) into its bf16 pieces in the MFMA
+        // shadow - about 4 VALU per MFMA gap, which the matrix pipe hides - and then issues the loads of tile
+        // k+2.  Between the two barriers only the LDS writes remain.  Measured without this (convert + write
+        // between the barriers): MFMA pipe busy 36 % even with the global loads removed.
+        constexpr int NP = SPLIT;                       // bf16 images per operand
+        constexpr int NPROD = SPLIT == 3 ? 6 : 3;       // MFMA products per accumulator and k16
+        bf16x4 pa[4][NP], pb[BROWS][NP];                // [.][0] hi, [.][1] lo, [.][2] mid
+        auto convert = [&](const f32x4& v, bf16x4* out) {
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
-                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
-                    al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
-                    if (SPLIT == 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
+            for (int e = 0; e < 4; e += 2) {
+                f32x2 rest = {v[e], v[e + 1]};
+                bf16x2 p = __builtin_convertvector(rest, bf16x2);
+                unsigned bits = __builtin_bit_cast(unsigned, p);
+                out[0][e] = p[0]; out[0][e + 1] = p[1];
+                rest[0] -= __builtin_bit_cast(float, bits << 16);
+                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+                if (SPLIT == 3) {
+                    p = __builtin_convertvector(rest, bf16x2);
+                    bits = __builtin_bit_cast(unsigned, p);
+                    out[2][e] = p[0]; out[2][e + 1] = p[1];
+                    rest[0] -= __builtin_bit_cast(float, bits << 16);
+                    rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
-                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
-                    if (SPLIT == 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {  // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        if (SPLIT == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+                p = __builtin_convertvector(rest, bf16x2);
+                out[1][e] = p[0]; out[1][e + 1] = p[1];
             }
-        }
-        const float* Ac = As;
-        const float* Bc = Bs;
+        };
+        auto write_tiles = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < (SPLIT ? 0 : BK / 8); ++ks) {
-            f32x4 a[TM], b[TN];
+            for (int j = 0; j < 4; ++j) {
+                const int o = (lr + 32 * j) * LDB + kq;
+                *reinterpret_cast<bf16x4*>(&Ah[o]) = pa[j][0];
+                *reinterpret_cast<bf16x4*>(&Al[o]) = pa[j][1];
+                if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&Am[o]) = pa[j][2];
+            }
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) {
+                const int o = (lr + 32 * j) * LDB + kq;
+                *reinterpret_cast<bf16x4*>(&Bh[o]) = pb[j][0];
+                *reinterpret_cast<bf16x4*>(&Bl[o]) = pb[j][1];
+                if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&Bm[o]) = pb[j][2];
+            }
+        };
+        auto mfma_group = [&](int ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+                ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                if (SPLIT == 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
+                if (SPLIT == 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&Ac[((wm * TM + i) * 32 + r) * LDK + ks * 8 + 4 * h]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bc[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
+                for (int j = 0; j < TN; ++j) {  // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (SPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        };
+        constexpr int NM = TM * TN * NPROD;              // MFMAs per k16 group
+        constexpr int NREAD = (TM + TN) * NP;            // ds_read_b128 per k16 group
+        constexpr int CONV_OPS = SPLIT == 3 ? 24 : 14;   // VALU per converted f32x4 (approx.)
+        constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM, VPG_B = (BROWS * CONV_OPS + NM - 1) / NM;
+        if (g.Ktot > 0) {
+            load_tiles_fast(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j]);
+            write_tiles();
+            load_tiles_fast(BK);
         }
         __syncthreads();
-        store_tiles();
+#ifdef SNN_STAMP
+        unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long st_last = __builtin_readcyclecounter();
+        const unsigned long long st_begin = st_last;
+#endif
+#pragma unroll 1
+        for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
+            mfma_group(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j]);
+            // shape the schedule: operand reads, then every MFMA followed by its share of the conversion VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG_A, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(0);
+            mfma_group(1);
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j]);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG_B, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(1);
+            load_tiles_fast(k0 + 2 * BK);
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+            write_tiles();
+            STAMP(4);
+            __syncthreads();
+            STAMP(5);
+        }
+#ifdef SNN_STAMP
+        if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+            st_acc[6] = __builtin_readcyclecounter() - st_begin;
+            st_acc[7] = st_begin;
+            for (int i = 0; i < 8; ++i) g_stamps[blockIdx.x * 8 + i] = st_acc[i];
+        }
+#endif
+    } else {
+        if (g.Ktot > 0) {  // a dgrad stride-phase class may have no tap at all: its pixels are plain zeros
+            load_tiles(0);
+            store_tiles();
+        }
         __syncthreads();
+
+        // Branch-free steady state (a tile past Ktot loads zeros and is never read): keeping the MFMA chain in
+        // one basic block lets the accumulators stay in their registers across iterations.
+    #pragma unroll 1
+        for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
+            load_tiles(k0 + BK);
+            // keep the prefetch ahead of the MFMA chain: its latency must be covered by the whole k-step
+            __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT) {
+    #pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
+                    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+                        ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
+                        al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                        if (SPLIT == 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+                        bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
+                        bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
+                        if (SPLIT == 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j) {  // small terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            if (SPLIT == 3) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                            }
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            const float* Ac = As;
+            const float* Bc = Bs;
+    #pragma unroll
+            for (int ks = 0; ks < (SPLIT ? 0 : BK / 8); ++ks) {
+                f32x4 a[TM], b[TN];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(&Ac[((wm * TM + i) * 32 + r) * LDK + ks * 8 + 4 * h]);
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bc[((wn * TN + j) * 32 + r) * LDK + ks * 8 + 4 * h]);
+    #pragma unroll
+                for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
@@ -320,11 +579,11 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
             if (m >= g.Mtot || n >= g.OC) continue;
             int64_t pix = m;
             if (DGRAD && g.stride > 1) {
-                int b = (int)(m % g.OWc);
-                int64_t t = m / g.OWc;
-                int a = (int)(t % g.OHc);
-                int64_t img = t / g.OHc;
-                pix = (img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
+                const unsigned t = (unsigned)m / (unsigned)g.OWc;
+                const int b = (int)((unsigned)m - t * (unsigned)g.OWc);
+                const unsigned img = t / (unsigned)g.OHc;
+                const int a = (int)(t - img * (unsigned)g.OHc);
+                pix = ((int64_t)img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
             }
             f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
             float* dst = out + pix * g.ldo + n;
@@ -339,6 +598,16 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_gather(co
         }
         __syncthreads();
     }
+#ifdef SNN_STAMP
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+        g_stamps2[blockIdx.x * 4 + 0] = st_kernel_begin;
+        g_stamps2[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_stamps2[blockIdx.x * 4 + 2] = xcc;
+        g_stamps2[blockIdx.x * 4 + 3] = hwid;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -738,13 +1007,40 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
         }
 }
 
+// Ordered reduction of the split-K slabs ws[splitk][n] -> dw[n].  KG thread groups share the slabs of one element
+// (each sums a contiguous run in slab order), then group 0 adds the KG partial sums in group order: fixed order,
+// bitwise reproducible, and the early layers (n of a few hundred, splitk of several hundred) are no longer one
+// latency-bound serial chain per thread.
+template <int KG>
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splitk,
                                int accumulate) {
-    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kThreads) {
-        float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += ws[(int64_t)k * n + e];
-        dw[e] = accumulate ? dw[e] + s : s;
+    constexpr int EL = kThreads / KG;
+    __shared__ float part[KG][EL];
+    const int el = threadIdx.x % EL, kg = threadIdx.x / EL;
+    const int64_t e = (int64_t)blockIdx.x * EL + el;
+    const int per = (splitk + KG - 1) / KG;
+    const int k0 = kg * per;
+    const int k1 = k0 + per < splitk ? k0 + per : splitk;
+    float s = 0.f;
+    if (e < n) {
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const float a = ws[(int64_t)k * n + e], b = ws[(int64_t)(k + 1) * n + e];
+            const float c = ws[(int64_t)(k + 2) * n + e], d = ws[(int64_t)(k + 3) * n + e];
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; k < k1; ++k) s += ws[(int64_t)k * n + e];
     }
+    if (KG > 1) {
+        part[kg][el] = s;
+        __syncthreads();
+        if (kg == 0) {
+            s = part[0][el];
+#pragma unroll
+            for (int g = 1; g < KG; ++g) s += part[g][el];
+        }
+    }
+    if (kg == 0 && e < n) dw[e] = accumulate ? dw[e] + s : s;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -759,17 +1055,24 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
                          int64_t ld_add, hipStream_t st, const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
-    SNN_REQUIRE(gm <= 0x7fffffff, "%s: too many pixels", name);
+    SNN_REQUIRE(g.Mtot < 0x7fffffffLL && (int64_t)g.IH * g.IW < 0x7fffffffLL, "%s: too many pixels", name);
+    const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
+    static const bool no_fast = getenv("SNN_CONV_NO_FAST") != nullptr;  // tuning / bisecting aid
+    const bool fast = vec && !no_fast && g.IC % BK == 0 && ntaps >= 1 && ntaps <= 31 &&
+                      (int64_t)g.IH * g.IW * g.ldi * 16 < 0x7fffffffLL && (int64_t)g.OC * g.KtotFull * 4 < 0x7fffffffLL;
     ConvGeom gg = g;
     gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend)));
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
     do {                                                                                                    \
         dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
-        if (vec)                                                                                            \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT>), grid, dim3(kThreads), 0, st, \
-                               in, wk, out, gg, addend, ld_add);                                            \
+        if (fast)                                                                                           \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
+                               st, in, wk, out, gg, addend, ld_add);                                        \
+        else if (vec)                                                                                       \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, false>), grid, dim3(kThreads), 0, \
+                               st, in, wk, out, gg, addend, ld_add);                                        \
         else                                                                                                \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0>), grid, dim3(kThreads), 0, st, \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0, false>), grid, dim3(kThreads), 0, st, \
                                in, wk, out, gg, addend, ld_add);                                            \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
@@ -822,6 +1125,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldi = ldx; g.ldo = ldy;
     g.Ktot = g.KtotFull = KH * KW * Cin;
+    g.nimg = (int)N;
     g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
     g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
@@ -845,6 +1149,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldi = lddy; g.ldo = lddx;
     g.KtotFull = KH * KW * Cout;
+    g.nimg = (int)N;
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     const bool split = g_backward_split != 0;
@@ -964,10 +1269,14 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
 #undef SNN_WGRAD_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
     const int64_t n = (int64_t)Cout * g.Ktot;
-    int64_t blocks = snn_ceil_div(n, kThreads);
-    if (blocks > SNN_MAX_BLOCKS) blocks = SNN_MAX_BLOCKS;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(kThreads), 0, st, workspace, dw, n, splitk,
-                       accumulate);
+#define SNN_REDUCE_LAUNCH(KG_)                                                                                  \
+    hipLaunchKernelGGL((k_wgrad_reduce<KG_>), dim3((unsigned)snn_ceil_div(n, kThreads / KG_)), dim3(kThreads), 0, \
+                       st, workspace, dw, n, splitk, accumulate)
+    if (splitk <= 8) SNN_REDUCE_LAUNCH(1);
+    else if (splitk <= 64) SNN_REDUCE_LAUNCH(4);
+    else if (splitk <= 256) SNN_REDUCE_LAUNCH(16);
+    else SNN_REDUCE_LAUNCH(64);
+#undef SNN_REDUCE_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad_reduce");
     return 0;
 }

@@ -9,14 +9,15 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows]
 ev.sort()
-# keep the last 60 % of the trace (steady state)
-t_lo = ev[0][0] + int(0.4 * (ev[-1][1] - ev[0][0]))
-ev = [e for e in ev if e[0] >= t_lo]
+# steady state: the window of the last `steps` optimiser kernels (one k_adamax per step)
+marks = [e[0] for e in ev if "k_adamax" in e[3]]
+if len(marks) > steps:
+    ev = [e for e in ev if marks[-steps - 1] <= e[0] < marks[-1]]
 span = ev[-1][1] - ev[0][0]
 per_q = defaultdict(int)
 for s, e, q, _ in ev:
     per_q[q] += e - s
-print(f"window {span / 1e6:.2f} ms, kernels {len(ev)}")
+print(f"window {span / 1e6:.2f} ms = {steps} steps, kernels {len(ev)}")
 for q, b in per_q.items():
     print(f"  queue {q}: busy {b / 1e6:.2f} ms ({100 * b / span:.1f} %)")
 # union busy time over all queues
