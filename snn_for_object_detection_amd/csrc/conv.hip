@@ -620,6 +620,7 @@ struct WgradGeom {
     int Ktot;
     int64_t pix_per_split;
     int tiles_m, tiles_n, splitk;
+    int nimg;
 };
 
 // Block tile (32*TM*WM) out-channels x (32*TN*WN) (tap,ci) columns; each wave owns TM x TN accumulators of
@@ -821,7 +822,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
     constexpr int DG = BMc / 4, XG = BNk / 4;                                  // 4-channel groups per pixel row
-    constexpr int DQ = (8 * DG + kThreads - 1) / kThreads, XQ = (8 * XG + kThreads - 1) / kThreads;  // quads / thread
+    // Loader thread -> (pixel quad = tid % 8, channel group = tid / 8 + 32 * pass): the 16 lanes of one LDS store
+    // group then write 8 quads (16 dwords) of two columns 4 apart, i.e. 16 dwords apart modulo the 32 banks -
+    // conflict-free.  (Consecutive lanes on consecutive channel groups, as before, put all 16 lanes on 2 bank
+    // pairs: measured 75 % of all LDS cycles were bank conflicts.)
+    constexpr int GPP = kThreads / 8;                                          // channel groups per pass
+    constexpr int DQ = (DG + GPP - 1) / GPP, XQ = (XG + GPP - 1) / GPP;        // passes per thread
     __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDB];
     __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDB];
     __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDB];
@@ -848,14 +854,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
     int64_t p_hi = p_lo + g.pix_per_split;
     if (p_hi > g.Mtot) p_hi = g.Mtot;
 
-    const int d_cq = (tid % DG) * 4, d_q0 = tid / DG;   // quad index of pass q: d_q0 + (kThreads / DG) * q
-    const int x_cq = (tid % XG) * 4, x_q0 = tid / XG;
-    const bool d_ok = (co0 + d_cq) < g.Cout;
-    const int kc = kc0 + x_cq;
-    const bool x_ok = kc < g.Ktot;
-    const int tap = (x_ok ? kc : 0) / g.Cin;
-    const int x_ci = (x_ok ? kc : 0) - tap * g.Cin;
-    const int x_kh = tap / g.KW, x_kw = tap - x_kh * g.KW;
+    const int quad = tid & 7, grp0 = tid >> 3;
+    int d_cq[DQ], x_cq[XQ], x_ci[XQ], x_kh[XQ], x_kw[XQ];
+    bool d_ok[DQ], x_ok[XQ];
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+        d_cq[q] = (grp0 + GPP * q) * 4;
+        d_ok[q] = (grp0 + GPP * q) < DG && (co0 + d_cq[q]) < g.Cout;
+    }
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        x_cq[q] = (grp0 + GPP * q) * 4;
+        const int kc = kc0 + x_cq[q];
+        x_ok[q] = (grp0 + GPP * q) < XG && kc < g.Ktot;
+        const int tap = (x_ok[q] ? kc : 0) / g.Cin;
+        x_ci[q] = (x_ok[q] ? kc : 0) - tap * g.Cin;
+        x_kh[q] = tap / g.KW;
+        x_kw[q] = tap - x_kh[q] * g.KW;
+    }
 
     int d_img = 0, d_oy = 0, d_ox = 0;
     int64_t d_p = p_lo + tid;
@@ -889,34 +905,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < DQ; ++q) {
-            const int quad = d_q0 + (kThreads / DG) * q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t p = p0 + quad * 4 + e;
-                const bool ok = (quad < 8) & (p < p_hi) & d_ok;
+                const bool ok = (p < p_hi) & d_ok[q];
                 const int64_t pc = ok ? p : 0;
-                f32x4 v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok ? co0 + d_cq : 0));
+                f32x4 v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok[q] ? co0 + d_cq[q] : 0));
                 rd[q][e] = ok ? v : zero;
             }
         }
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int quad = x_q0 + (kThreads / XG) * q;
+        for (int e = 0; e < 4; ++e) {
+            const int row = quad * 4 + e;
+            const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
+            const bool pok = Pinfo[slot][row][3] != 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = (quad < 8 ? quad : 0) * 4 + e;
-                const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
-                const bool pok = Pinfo[slot][row][3] != 0;
-                const int iy = y0 + x_kh, ix = x0 + x_kw;
-                const bool ok = (quad < 8) & pok & x_ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+            for (int q = 0; q < XQ; ++q) {
+                const int iy = y0 + x_kh[q], ix = x0 + x_kw[q];
+                const bool ok = pok & x_ok[q] & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
                 const int iyc = min(max(iy, 0), g.H - 1), ixc = min(max(ix, 0), g.W - 1);
-                f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(ibase + iyc * g.W + ixc) * g.ldx + x_ci);
+                f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(ibase + iyc * g.W + ixc) * g.ldx + x_ci[q]);
                 rx[q][e] = ok ? v : zero;
             }
         }
     };
     // 4 pixels x 4 channels -> per channel the 4 pixels as bf16 hi / lo, 8 bytes each
-    auto store_quad = [&](const f32x4 (&v)[4], __bf16* hi_img, __bf16* lo_img, int col0, int quad) {
+    auto store_quad = [&](const f32x4 (&v)[4], __bf16* hi_img, __bf16* lo_img, int col0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 hi, lo;
@@ -931,15 +945,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int q = 0; q < DQ; ++q) {
-            const int quad = d_q0 + (kThreads / DG) * q;
-            if (quad < 8) store_quad(rd[q], Dh, Dl, d_cq, quad);
-        }
+        for (int q = 0; q < DQ; ++q)
+            if (grp0 + GPP * q < DG) store_quad(rd[q], Dh, Dl, d_cq[q]);
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int quad = x_q0 + (kThreads / XG) * q;
-            if (quad < 8) store_quad(rx[q], Xh, Xl, x_cq, quad);
-        }
+        for (int q = 0; q < XQ; ++q)
+            if (grp0 + GPP * q < XG) store_quad(rx[q], Xh, Xl, x_cq[q]);
     };
 
     f32x16 acc[TM][TN];
@@ -988,6 +998,271 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
         }
         __syncthreads();
         store_tiles();
+        __syncthreads();
+        slot ^= 1;
+    }
+
+    float* slab = ws + (int64_t)z * g.Cout * (int64_t)g.Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int kcol = kc0 + (wn * TN + j) * 32 + r;
+            if (kcol >= g.Ktot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < g.Cout) slab[(int64_t)co * g.Ktot + kcol] = acc[i][j][e];
+            }
+        }
+}
+
+// Pipelined form of k_conv_wgrad_split (host-checked: one pixel split of x spans < 2 GiB, so 32-bit byte offsets
+// relative to the split's first image address every gathered pixel).  Same arithmetic and accumulation order as
+// k_conv_wgrad_split; what changes is WHEN things happen, as in the pipelined k_conv_gather loop:
+//   * raw buffer loads with hardware range checking (offset 0xFFFFFFFF -> zeros): no clamps, selects or 64-bit
+//     address arithmetic; dy rows past the split's last pixel fall off the end of the buffer resource;
+//   * tile k+1 is converted to its bf16 pieces in the shadow of tile k's MFMAs and the loads of tile k+2 are
+//     issued before the barrier; between the two barriers only the LDS writes remain.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ ws, WgradGeom g) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
+    constexpr int DG = BMc / 4, XG = BNk / 4;
+    constexpr int GPP = kThreads / 8;
+    constexpr int DQ = (DG + GPP - 1) / GPP, XQ = (XG + GPP - 1) / GPP;
+    __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDB];
+    __shared__ __attribute__((aligned(16))) int Pinfo[2][WB_K][4];  // {byte offset of the pixel origin, y0, x0, valid}
+
+    const int tid = threadIdx.x;
+    const int lane_id = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane_id & 31, h = lane_id >> 5;
+
+    const int tiles = g.tiles_m * g.tiles_n;
+    int L = blockIdx.x, z, tile;
+    if (g.splitk % 8 == 0) {
+        z = (L % 8) + 8 * (L / (8 * tiles));
+        tile = (L / 8) % tiles;
+    } else {
+        z = L / tiles;
+        tile = L % tiles;
+    }
+    const int co0 = (tile % g.tiles_m) * BMc;
+    const int kc0 = (tile / g.tiles_m) * BNk;
+    const unsigned p_lo = (unsigned)((int64_t)z * g.pix_per_split);
+    unsigned p_hi = p_lo + (unsigned)g.pix_per_split;
+    if (p_hi > (unsigned)g.Mtot) p_hi = (unsigned)g.Mtot;
+    if (p_lo >= p_hi) p_hi = p_lo;  // an empty split still writes its (zero) slab
+
+    // ---- buffer resources: dy rows of this split, x from the split's first image on
+    const unsigned opix = (unsigned)(g.Ho * g.Wo), ipix = (unsigned)(g.H * g.W);
+    const unsigned img_lo = p_lo / opix;
+    __amdgpu_buffer_rsrc_t rs_d, rs_x;
+    {
+        const int64_t dbytes = p_hi > p_lo ? (((int64_t)(p_hi - p_lo) - 1) * g.lddy + g.Cout) * 4 : 0;
+        rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (int64_t)p_lo * g.lddy), 0, (int)dbytes,
+                                                 0x00020000);
+        const int64_t xbytes = ((((int64_t)g.nimg - img_lo) * ipix - 1) * g.ldx + g.Cin) * 4;
+        rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)img_lo * ipix * g.ldx), 0,
+                                                 xbytes > 0x7fffffffLL ? 0x7fffffff : (xbytes < 0 ? 0 : (int)xbytes), 0x00020000);
+    }
+
+    // ---- loader geometry: thread -> (pixel quad, channel group + 32 * pass), see k_conv_wgrad_split
+    const int quad = tid & 7, grp0 = tid >> 3;
+    int d_off[DQ];       // byte offset of (pixel quad*4, channel group) inside a stage; -1: channels past Cout
+    int x_tapoff[XQ];    // byte offset of (tap, ci) relative to a pixel origin
+    int x_kh[XQ], x_kw[XQ], x_cq[XQ], d_cq[DQ];
+    bool x_ok[XQ];
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+        d_cq[q] = (grp0 + GPP * q) * 4;
+        const bool ok = (grp0 + GPP * q) < DG && (co0 + d_cq[q]) < g.Cout;
+        d_off[q] = ok ? ((quad * 4) * (int)g.lddy + co0 + d_cq[q]) * 4 : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        x_cq[q] = (grp0 + GPP * q) * 4;
+        const int kc = kc0 + x_cq[q];
+        x_ok[q] = (grp0 + GPP * q) < XG && kc < g.Ktot;
+        const int kcc = x_ok[q] ? kc : 0;
+        const int tap = kcc / g.Cin, ci = kcc - tap * g.Cin;
+        x_kh[q] = tap / g.KW;
+        x_kw[q] = tap - x_kh[q] * g.KW;
+        x_tapoff[q] = ((x_kh[q] * g.W + x_kw[q]) * (int)g.ldx + ci) * 4;
+    }
+
+    // ---- pixel decode, 32 lanes, one stage ahead (carries instead of divisions inside the loop)
+    int d_img = 0, d_oy = 0, d_ox = 0;
+    unsigned d_p = p_lo + tid;
+    if (tid < WB_K) {
+        const unsigned pp = d_p < (unsigned)g.Mtot ? d_p : 0u;
+        const unsigned t = pp / (unsigned)g.Wo;
+        d_ox = (int)(pp - t * (unsigned)g.Wo);
+        const unsigned im = t / (unsigned)g.Ho;
+        d_oy = (int)(t - im * (unsigned)g.Ho);
+        d_img = (int)(im - img_lo);
+    }
+    auto decode = [&](int slot) {
+        if (tid < WB_K) {
+            const int y0 = d_oy * g.stride - g.pad, x0 = d_ox * g.stride - g.pad;
+            int4 info;
+            info.x = ((d_img * (int)ipix + y0 * g.W + x0) * (int)g.ldx) * 4;
+            info.y = y0;
+            info.z = x0;
+            info.w = d_p < p_hi ? 1 : 0;
+            *reinterpret_cast<int4*>(&Pinfo[slot][tid][0]) = info;
+            d_p += WB_K;
+            d_ox += WB_K;
+            while (d_ox >= g.Wo) {
+                d_ox -= g.Wo;
+                if (++d_oy == g.Ho) {
+                    d_oy = 0;
+                    ++d_img;
+                }
+            }
+        }
+    };
+
+    f32x4 rd[DQ][4], rx[XQ][4];
+    auto load_tiles = [&](unsigned p0, int slot) {
+        const int dstage = (int)(p0 - p_lo) * (int)g.lddy * 4;  // scalar
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int4 info = *reinterpret_cast<const int4*>(&Pinfo[slot][quad * 4 + e][0]);
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                const int voff = d_off[q] < 0 ? -1 : d_off[q] + e * (int)g.lddy * 4 + dstage;
+                rd[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, voff, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) {
+                const int iy = info.y + x_kh[q], ix = info.z + x_kw[q];
+                const bool ok = (info.w != 0) & x_ok[q] & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+                const int voff = ok ? info.x + x_tapoff[q] : -1;
+                rx[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0));
+            }
+        }
+    };
+    // 4 pixels x 4 channels -> per channel the 4 pixels as bf16 hi / lo (8 bytes each), kept in registers
+    bf16x4 pd[DQ][4][2], px[XQ][4][2];
+    auto convert_quad = [&](const f32x4 (&v)[4], bf16x4 (&out)[4][2]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                f32x2 rest = {v[e][c], v[e + 1][c]};
+                bf16x2 pp = __builtin_convertvector(rest, bf16x2);
+                const unsigned bits = __builtin_bit_cast(unsigned, pp);
+                out[c][0][e] = pp[0]; out[c][0][e + 1] = pp[1];
+                rest[0] -= __builtin_bit_cast(float, bits << 16);
+                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+                pp = __builtin_convertvector(rest, bf16x2);
+                out[c][1][e] = pp[0]; out[c][1][e + 1] = pp[1];
+            }
+    };
+    auto write_tiles = [&]() {
+#pragma unroll
+        for (int q = 0; q < DQ; ++q)
+            if (grp0 + GPP * q < DG) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    *reinterpret_cast<bf16x4*>(&Dh[(d_cq[q] + c) * LDB + quad * 4]) = pd[q][c][0];
+                    *reinterpret_cast<bf16x4*>(&Dl[(d_cq[q] + c) * LDB + quad * 4]) = pd[q][c][1];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+            if (grp0 + GPP * q < XG) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    *reinterpret_cast<bf16x4*>(&Xh[(x_cq[q] + c) * LDB + quad * 4]) = px[q][c][0];
+                    *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDB + quad * 4]) = px[q][c][1];
+                }
+            }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mfma_group = [&](int ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+            ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
+            al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+            bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
+            bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    constexpr int NM = TM * TN * 3;
+    constexpr int NREAD = (TM + TN) * 2;
+    constexpr int VPG_D = (DQ * 56 + NM - 1) / NM, VPG_X = (XQ * 56 + NM - 1) / NM;
+
+    decode(0);
+    __syncthreads();
+    load_tiles(p_lo, 0);
+    decode(1);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) convert_quad(rd[q], pd[q]);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) convert_quad(rx[q], px[q]);
+    write_tiles();
+    load_tiles(p_lo + WB_K, 1);
+    decode(0);
+    __syncthreads();
+
+    int slot = 0;  // Pinfo slot of tile k+2
+#pragma unroll 1
+    for (unsigned p0 = p_lo; p0 < p_hi; p0 += WB_K) {
+        mfma_group(0);
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) convert_quad(rd[q], pd[q]);
+        __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPG_D, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) convert_quad(rx[q], px[q]);
+        __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPG_X, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tiles(p0 + 2 * WB_K, slot);
+        __syncthreads();
+        write_tiles();
+        decode(slot ^ 1);
         __syncthreads();
         slot ^= 1;
     }
@@ -1210,8 +1485,11 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     const WgradTile t = wgrad_tile(Cout, (int)Ktot, split_mode);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
     // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time);
-    // the bf16x3 variants of the three large tiles need > 168 registers: 2 blocks per CU
-    const int resident = (split_mode && t.id <= 2) ? 2 : t.blocks_per_cu;
+    // residency of the bf16x3 (pipelined) variants by registers / LDS
+    static const int split_resident[6] = {3, 2, 2, 3, 3, 3};  // measured optimum (sweep over 2..6) per tile variant
+    int resident = split_mode ? split_resident[t.id] : t.blocks_per_cu;
+    if (split_mode && t.id == 0 && Cout <= t.bm) resident = 2;  // one row of tiles: fewer, longer splits win
+    if (const char* force = getenv("SNN_WGRAD_RESIDENT")) resident = atoi(force) > 0 ? atoi(force) : resident;  // tuning aid
     int64_t s = ((int64_t)resident * SNN_NUM_CU) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
@@ -1241,6 +1519,12 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);
     const WgradTile t = wgrad_tile(Cout, g.Ktot, g_backward_split && Cin % 4 == 0 && Cout % 4 == 0);
+    g.nimg = (int)N;
+    // pipelined kernel: 32-bit byte offsets relative to the first image of a pixel split
+    const int64_t span_pix = g.pix_per_split * (int64_t)stride * stride + 3 * (int64_t)H * W;
+    static const bool no_pipe = getenv("SNN_WGRAD_NO_PIPE") != nullptr;  // tuning / bisecting aid
+    const bool pipe = vec && g_backward_split && !no_pipe && g.Mtot < 0x7fffffffLL && span_pix * ldx * 4 < 0x7fffffffLL &&
+                      g.pix_per_split * lddy * 4 < 0x7fffffffLL && (int64_t)H * W * ldx * 4 < 0x7fffffffLL;
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
     g.splitk = splitk;
@@ -1250,7 +1534,10 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (vec && g_backward_split)                                                                           \
+        if (pipe)                                                                                              \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,    \
+                               workspace, g);                                                                  \
+        else if (vec && g_backward_split)                                                                      \
             hipLaunchKernelGGL((k_conv_wgrad_split<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,   \
                                workspace, g);                                                                  \
         else if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
