@@ -306,12 +306,15 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     pl.cvb = cvb;
     pl.gy = (int)snn_ceil_div(cv, cvb);
     int P = kThreads / cvb;
-    int64_t gx = snn_ceil_div(M, (int64_t)P * kBwdNP);
+    // Every block owns a contiguous run of pixel rows (P pixels each) of EQUAL length, processed kBwdNP rows at a
+    // time with the tail masked: all blocks are resident at once and finish together.  (A grid-stride loop over
+    // kBwdNP-row groups left e.g. 713 groups on 512 blocks: 2 rounds for 1.4 rounds of work.)
+    const int64_t rows = snn_ceil_div(M, (int64_t)P);
     int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;  // 64 KiB of LDS per block -> 2 blocks per CU
     cap = cap / pl.gy;
     if (cap < 1) cap = 1;
-    if (gx > cap) gx = cap;
-    pl.gx = (int)gx;
+    const int64_t rpb = snn_ceil_div(rows, rows < cap ? rows : cap);
+    pl.gx = (int)snn_ceil_div(rows, rpb);
     return pl;
 }
 
@@ -342,14 +345,18 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     }
     const float one_m_cmem = 1.0f - p.c_mem;
     const float one_p_csyn = 1.0f + p.c_syn;
-    for (int64_t mb = (int64_t)blockIdx.x * P * NP; mb < M; mb += (int64_t)gridDim.x * P * NP) {
+    const int64_t rows = (M + P - 1) / P;
+    const int64_t rpb = (rows + gridDim.x - 1) / gridDim.x;  // pixel rows per block (see bwd_plan)
+    const int64_t row_lo = (int64_t)blockIdx.x * rpb;
+    const int64_t row_hi = row_lo + rpb < rows ? row_lo + rpb : rows;
+    for (int64_t rb = row_lo; rb < row_hi; rb += NP) {
         int64_t mq[NP];
         bool ok[NP];
         V gv[NP], gi[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            mq[q] = mb + (int64_t)q * P + ps;
-            ok[q] = lane_ok && mq[q] < M;
+            mq[q] = (rb + q) * P + ps;
+            ok[q] = lane_ok && rb + q < row_hi && mq[q] < M;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) lane<VEC>(gv[q], j) = lane<VEC>(gi[q], j) = 0.0f;
             if (NEURON != SNN_NEURON_NONE && ok[q]) {
