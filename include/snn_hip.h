@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 2
+#define SNN_ABI_VERSION 3
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -106,9 +106,13 @@ int snn_get_forward_precision(void);
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                    int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);
+/* dgrad takes TWO optional addends (dx = conv^T(dy) + addend + addend2): a tensor consumed by a convolution, a
+ * residual shortcut and a Dense pass-through (the YOLO bottleneck inside a C2f block) gets its whole gradient in one
+ * epilogue instead of two extra add passes. */
 int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                     int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);
+                     int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend,
+                     const float* addend2, int64_t ld_addend2, void* stream);
 int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, int accumulate,
@@ -156,11 +160,15 @@ int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total, int C,
  *   v0/i0 NULL -> initial state (v = v_leak, i = 0); vT/iT NULL -> final state not written.
  *   vdec (training) receives what the backward scan needs per step: LIF the pre-reset potential vd[t],
  *   SLI the potential BEFORE the step, SYNAPSE the new concentration p[t].
+ *   addend (may be NULL; [T][M][C-slice], pixel stride ld_addend): out[t] = neuron output + addend[t] - the residual
+ *   shortcut (generator.py:145-146, stack + sum) folded into the store; not allowed with LI_TANH, whose backward
+ *   scan reads its own output.
  * Layout: y/out/vdec are [T][M][C-slice] with pixel strides ldy/ldo (vdec dense, ld = C). */
 int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
                           const float* alpha, const float* beta,
                           const float* v0, const float* i0,
-                          float* out, int64_t ldo, float* vT, float* iT, float* vdec,
+                          float* out, int64_t ldo, const float* addend, int64_t ld_addend,
+                          float* vT, float* iT, float* vdec,
                           int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
 
 /* Reverse-time scan (BPTT through the neuron, SuperSpike surrogate dz/du = 1/(alpha|u|+1)^2,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NeuronParams(Structure):
@@ -38,7 +38,8 @@ SIGNATURES = {
     "snn_set_forward_precision": (c_int, [_I]),
     "snn_get_forward_precision": (c_int, []),
     "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
-    "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L,
+                                 _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I]),
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
@@ -48,7 +49,7 @@ SIGNATURES = {
     "snn_bn_stats_from_sums": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "snn_bn_bwd_reduce": (c_int, [_P, _I, _L, _I, _P, _P]),
     "snn_bn_bwd_coef": (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _L, _I,
+    "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),
     "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),
     "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
@@ -88,7 +89,7 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.snn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnn_hip.so ABI {lib.snn_abi_version()} != binding {ABI_VERSION}: rebuild")
-    # optional process-wide arithmetic overrides (defaults: forward exact fp32, backward bf16x3)
+    # optional process-wide arithmetic overrides (defaults: forward bf16x6, backward bf16x3)
     fwd = os.environ.get("SNN_FORWARD_PRECISION")
     if fwd:
         lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3}[fwd])

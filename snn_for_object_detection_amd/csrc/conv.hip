@@ -94,7 +94,8 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST>
 __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
-                                                          const float* __restrict__ addend, int64_t ld_add) {
+                                                          const float* __restrict__ addend, int64_t ld_add,
+                                                          const float* __restrict__ addend2, int64_t ld_add2) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
@@ -589,11 +590,17 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             float* dst = out + pix * g.ldo + n;
             if (ovec && n + 3 < g.OC) {
                 if (addend) v += *reinterpret_cast<const f32x4*>(addend + pix * ld_add + n);  // fused accumulation
+                if (addend2) v += *reinterpret_cast<const f32x4*>(addend2 + pix * ld_add2 + n);
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (n + q < g.OC) dst[q] = addend ? v[q] + addend[pix * ld_add + n + q] : v[q];
+                    if (n + q < g.OC) {
+                        float o = v[q];
+                        if (addend) o += addend[pix * ld_add + n + q];
+                        if (addend2) o += addend2[pix * ld_add2 + n + q];
+                        dst[q] = o;
+                    }
             }
         }
         __syncthreads();
@@ -1327,7 +1334,7 @@ static int g_forward_split = 3;
 
 template <bool DGRAD, int SPLIT>
 static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
-                         int64_t ld_add, hipStream_t st, const char* name) {
+                         int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(g.Mtot < 0x7fffffffLL && (int64_t)g.IH * g.IW < 0x7fffffffLL, "%s: too many pixels", name);
@@ -1336,19 +1343,20 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     const bool fast = vec && !no_fast && g.IC % BK == 0 && ntaps >= 1 && ntaps <= 31 &&
                       (int64_t)g.IH * g.IW * g.ldi * 16 < 0x7fffffffLL && (int64_t)g.OC * g.KtotFull * 4 < 0x7fffffffLL;
     ConvGeom gg = g;
-    gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend)));
+    gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
+                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
     do {                                                                                                    \
         dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
         if (fast)                                                                                           \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
-                               st, in, wk, out, gg, addend, ld_add);                                        \
+                               st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else if (vec)                                                                                       \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, false>), grid, dim3(kThreads), 0, \
-                               st, in, wk, out, gg, addend, ld_add);                                        \
+                               st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else                                                                                                \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0, false>), grid, dim3(kThreads), 0, st, \
-                               in, wk, out, gg, addend, ld_add);                                            \
+                               in, wk, out, gg, addend, ld_add, addend2, ld_add2);                        \
     } while (0)
     if (g.OC <= 32) SNN_CONV_LAUNCH(32, 4, 1);
     else if (g.OC <= 64) SNN_CONV_LAUNCH(64, 2, 2);
@@ -1407,14 +1415,16 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
     if (g_forward_split == 3)
-        return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
-    return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, (hipStream_t)stream, "snn_conv2d_fwd");
+        return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+    return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
 extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                                const float* addend, int64_t ld_addend, void* stream) {
+                                const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2,
+                                void* stream) {
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
+    SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv2d_dgrad: addend2 pixel stride smaller than channel count");
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(lddy >= Cout && lddx >= Cin, "snn_conv2d_dgrad: pixel stride smaller than channel count");
     SNN_REQUIRE(!addend || ld_addend >= Cin, "snn_conv2d_dgrad: addend pixel stride smaller than channel count");
@@ -1440,10 +1450,10 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
-                                                    "snn_conv2d_dgrad")
-                           : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, (hipStream_t)stream,
-                                                    "snn_conv2d_dgrad");
+            int rc = split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                    (hipStream_t)stream, "snn_conv2d_dgrad")
+                           : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                    (hipStream_t)stream, "snn_conv2d_dgrad");
             if (rc) return rc;
         }
     return 0;

@@ -178,8 +178,8 @@ template <int NEURON, int VEC, bool SAVE>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     const float* __restrict__ y, int64_t ldy, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ v0, const float* __restrict__ i0, float* __restrict__ out, int64_t ldo,
-    float* __restrict__ vT, float* __restrict__ iT, float* __restrict__ vdec, int T, int64_t M, int C,
-    snn_neuron_params p) {
+    const float* __restrict__ addend, int64_t ld_add, float* __restrict__ vT, float* __restrict__ iT,
+    float* __restrict__ vdec, int T, int64_t M, int C, snn_neuron_params p) {
     typedef typename Vec<VEC>::type V;
     const int cv = C / VEC;
     const int64_t total = M * cv;
@@ -248,6 +248,11 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                         lane<VEC>(o, j) = (NEURON == SNN_NEURON_LI_TANH) ? tanhf(v_dec) : v_dec;
                     }
                 }
+            }
+            if (addend) {  // residual shortcut folded into the store
+                V ad = Vec<VEC>::load(addend + row * ld_add + c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(ad, j);
             }
             Vec<VEC>::store(out + row * ldo + c, o);
             if (SAVE && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
@@ -714,27 +719,33 @@ extern "C" int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total
     do {                                                                                                          \
         if (vec == 4)                                                                                             \
             hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 4, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
-                               y, ldy, alpha, beta, v0, i0, out, ldo, vT, iT, vdec, T, M, C, *p);                  \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p); \
         else                                                                                                      \
             hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 1, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
-                               y, ldy, alpha, beta, v0, i0, out, ldo, vT, iT, vdec, T, M, C, *p);                  \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p); \
     } while (0)
 
 extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta,
-                                     const float* v0, const float* i0, float* out, int64_t ldo, float* vT, float* iT,
-                                     float* vdec, int T, int64_t M, int C, const snn_neuron_params* p, void* stream) {
+                                     const float* v0, const float* i0, float* out, int64_t ldo, const float* addend,
+                                     int64_t ld_addend, float* vT, float* iT, float* vdec, int T, int64_t M, int C,
+                                     const snn_neuron_params* p, void* stream) {
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
+    SNN_REQUIRE(!addend || (ld_addend >= C && neuron != SNN_NEURON_LI_TANH),
+                "snn_affine_neuron_fwd: addend needs ld_addend >= C and is not allowed with LI_TANH");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && ldo >= C, "snn_affine_neuron_fwd: bad shape");
     SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_affine_neuron_fwd: alpha/beta must come together");
     SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_fwd: bad neuron %d",
                 neuron);
     int vec = (C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned16(y) && aligned16(out) && aligned16(alpha) &&
-               aligned16(beta) && aligned16(v0) && aligned16(i0) && aligned16(vT) && aligned16(iT) && aligned16(vdec))
+               aligned16(beta) && aligned16(v0) && aligned16(i0) && aligned16(vT) && aligned16(iT) && aligned16(vdec) &&
+               (!addend || (ld_addend % 4 == 0 && aligned16(addend))))
                   ? 4
                   : 1;
     int64_t total = M * (C / vec);
-    int64_t blocks = snn_ceil_div(total, kThreads);
-    if (blocks > SNN_MAX_BLOCKS) blocks = SNN_MAX_BLOCKS;
+    // every thread scans the same number of (pixel, channel group) items over all T (grid-stride, tail masked) and
+    // all blocks are resident at once: a capped grid with 1.4 items per thread would run 2 rounds for 1.4 of work
+    const int64_t per_thread = snn_ceil_div(total, (int64_t)SNN_MAX_BLOCKS * kThreads);
+    int64_t blocks = snn_ceil_div(total, kThreads * per_thread);
     dim3 grid((unsigned)blocks);
     switch (neuron) {
         case SNN_NEURON_NONE: SNN_DISPATCH_FWD(SNN_NEURON_NONE, false); break;

@@ -9,6 +9,7 @@ of the hot path happens in ``libsnn_hip.so``.  No CPU / eager fallback exists: t
 not on a HIP device raise.
 """
 
+import os
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
@@ -298,17 +299,22 @@ class GradSlot:
         return acc
 
 
+FUSE_OUTER_ADDEND = not os.environ.get("SNN_NO_OUTER_ADDEND")  # bisecting aid
+
+
 class GradAccumulator:
     """Shared by the aliases a block hands to its branches (``fanout``): lets the FIRST data-gradient
     convolution that runs for the fanned-out tensor add the gradients other branches have already produced
     in its epilogue (``snn_conv2d_dgrad(addend=...)``) instead of a separate add pass afterwards."""
 
-    __slots__ = ("deposits", "result", "fused")
+    __slots__ = ("deposits", "result", "fused", "outer")
 
     def __init__(self):
         self.deposits = {}    # alias index -> gradient produced for that alias by a pass-through consumer
         self.result = None    # dx written by the fusing convolution
         self.fused = {}       # alias index -> deposit that went into ``result``
+        self.outer = None     # (accumulator, alias index) of the enclosing fanout when the fanned-out tensor is
+        #                       itself an alias (Residual inside Dense: the YOLO bottleneck)
 
     def deposit(self, key, g: torch.Tensor) -> None:
         if self.result is None and g is not None:
@@ -365,8 +371,9 @@ class _Conv2d(Function):
             wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
             _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
             dx = _new_cl((T, B), Cin, H, W, x)
-            addend, ld_add = None, 0
+            addend, ld_add, addend2, ld_add2 = None, 0, None, 0
             acc = ctx.acc
+            outer_fused = None
             if acc is not None and acc[0].result is None and acc[0].deposits:
                 # another branch of the block already produced its gradient for this tensor: add it here
                 key, other = next(iter(acc[0].deposits.items()))
@@ -374,11 +381,27 @@ class _Conv2d(Function):
                 if tuple(other.shape) == tuple(dx.shape):
                     addend, ld_add = other.data_ptr(), cl_stride(other)
                     acc[0].fused[key] = acc[0].deposits.pop(key)
+            if (acc is not None and acc[0].result is None and not acc[0].deposits and acc[0].outer is not None
+                    and FUSE_OUTER_ADDEND):
+                # the tensor is itself one alias of an enclosing fanout whose other consumer already deposited
+                # its gradient (bottleneck input: conv + residual shortcut + Dense pass-through): second addend
+                o_acc, o_key = acc[0].outer
+                if o_acc.result is None and len(o_acc.deposits) == 1 and o_key not in o_acc.deposits:
+                    key2, other2 = next(iter(o_acc.deposits.items()))
+                    other2 = _raw_to_cl(other2)
+                    if tuple(other2.shape) == tuple(dx.shape):
+                        addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
+                        outer_fused = (o_acc, o_key, key2)
             _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
-                      Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, st)
+                      Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, st)
             if acc is not None and acc[0].result is None:
                 acc[0].result = dx
                 acc[0].fused[acc[1]] = dx
+            if outer_fused is not None:
+                o_acc, o_key, key2 = outer_fused
+                o_acc.fused[key2] = o_acc.deposits.pop(key2)
+                o_acc.fused[o_key] = dx   # what the inner fanout will hand back for this alias
+                o_acc.result = dx
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
             if ctx.slot is not None and USE_WGRAD_STREAM:
@@ -434,12 +457,15 @@ _SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
 class _AffineNeuron(Function):
     """[BatchNorm2d (per-timestep batch statistics)] -> [LIF | LI | LI+Tanh | nothing], fused.
 
-    inputs : y[T,B,C,H,W], gamma[C]|None, bias[C]|None, v0|None, i0|None, + non-tensor config
+    inputs : y[T,B,C,H,W], gamma[C]|None, bias[C]|None, v0|None, i0|None, addend[T,B,C,H,W]|None, + non-tensor config
     outputs: out[T,B,C,H,W], vT[B,C,H,W], iT[B,C,H,W]  (vT/iT are dummies when neuron == NONE)
+
+    ``addend`` is a residual shortcut folded into the output store: out = neuron(norm(y)) + addend
+    (generator.py:145-146 does stack + sum as a separate pass); its gradient is g_out itself.
     """
 
     @staticmethod
-    def forward(ctx, y, gamma, bias, v0, i0, cfg):
+    def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
          sync_group) = cfg
         _require_device(y, "norm/neuron input")
@@ -496,9 +522,19 @@ class _AffineNeuron(Function):
             v0 = _expand_state(v0, (B, C, H, W), dev)
         if i0 is not None:
             i0 = _expand_state(i0, (B, C, H, W), dev)
+        ctx.addend_acc = None
+        ad_ptr, ld_ad = None, 0
+        if addend is not None:
+            if neuron == _hip.NEURON_LI_TANH:
+                raise RuntimeError("a fused shortcut is not supported after LI+Tanh (its backward reads the output)")
+            ctx.addend_acc = _acc_of(addend)
+            addend = _raw_to_cl(addend)
+            if tuple(addend.shape) != (T, B, C, H, W):
+                raise RuntimeError("Residual merge: branch outputs differ in shape")
+            ad_ptr, ld_ad = addend.data_ptr(), cl_stride(addend)
         _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
-                  out.data_ptr(), cl_stride(out), _ptr(vT) if has_state else None, _ptr(iT) if has_state else None,
-                  _ptr(vdec), T, M, C, params, st)
+                  out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
+                  _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params, st)
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
         ctx.sync_group = sync_group if (has_bn and not use_running) else None
@@ -521,6 +557,11 @@ class _AffineNeuron(Function):
         st = _stream()
         dev = y.device
         has_state = neuron != _hip.NEURON_NONE
+        g_addend = None
+        if g_out is not None and ctx.needs_input_grad[5]:
+            g_addend = g_out
+            if ctx.addend_acc is not None:  # lets the shortcut's producer-side dgrad add it in its epilogue
+                ctx.addend_acc[0].deposit(ctx.addend_acc[1], g_out)
         if g_out is None:
             g_out = torch.zeros((T, B, H, W, C), device=dev, dtype=_F32)
             g_out = _cl_view(g_out)
@@ -589,7 +630,7 @@ class _AffineNeuron(Function):
                           coef[1].data_ptr(), coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
         if need_y:
             dy = _cl_view(gx)
-        return dy, dgamma, dbias, g_v0, g_i0, None
+        return dy, dgamma, dbias, g_v0, g_i0, g_addend, None
 
 
 def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
@@ -601,13 +642,20 @@ def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
 
 
 def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = None, bn=None,
-                  params: Optional[NeuronParams] = None, dest: Optional[Dest] = None):
-    """Fused ``[Norm] -> [neuron]`` over a sequence or a single step.
+                  params: Optional[NeuronParams] = None, dest: Optional[Dest] = None,
+                  addend: Optional[torch.Tensor] = None):
+    """Fused ``[Norm] -> [neuron] [+ addend]`` over a sequence or a single step.
 
     ``bn`` is an ``nn.BatchNorm2d``-like module (weight, bias, running stats, eps, momentum, training)
-    or None.  Returns ``(out, NeuronState | None)``.
+    or None; ``addend`` (same shape as the output) is a residual shortcut added in the output store.
+    Returns ``(out, NeuronState | None)``.
     """
     seq, single = as_sequence(y)
+    if addend is not None:
+        acc = _acc_of(addend)
+        addend, _ = as_sequence(addend)
+        if acc is not None:
+            addend._snn_acc = acc
     params = params or neuron_params()
     has_bn = bn is not None
     gamma = bias = rm = rv = None
@@ -631,7 +679,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
            dest, sync_group)
-    out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, cfg)
+    out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, addend, cfg)
     if neuron == _hip.NEURON_NONE:
         new_state = None
     elif neuron == _hip.NEURON_SYNAPSE:
@@ -735,7 +783,7 @@ class _Fanout(Function):
     @staticmethod
     def forward(ctx, x, n: int):
         ctx.acc = GradAccumulator()
-        ctx.outer = _acc_of(x)
+        ctx.outer = ctx.acc.outer = _acc_of(x)
         outs = []
         for k in range(n):
             t = torch.empty(0, device=x.device, dtype=x.dtype)

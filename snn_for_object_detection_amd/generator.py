@@ -16,6 +16,7 @@ with ``T = 1``, which keeps the reference's calling protocol for streaming ``pre
 """
 
 import inspect
+import os
 from typing import Any, List, Optional, Tuple, Union
 
 import torch
@@ -80,6 +81,19 @@ class BlockGen(nn.Module):
         # the first branch that is a bare Pass (its content = the block input, which the PRODUCER of that
         # input can write there directly when this block is the next layer of the parent branch)
         self._offsets = [sum(self._branch_channels[:k]) for k in range(len(self._branch_channels))]
+        # Residual([[..., Norm, LIF], [Pass]]) (the YOLO bottleneck): the shortcut is added in the LIF kernel's
+        # output store instead of a separate stack + sum pass: (main branch, pass branch) or None
+        self._fused_shortcut: Optional[Tuple[int, int]] = None
+        if self.merge == "residual" and len(self.net) == 2 and not os.environ.get("SNN_NO_FUSED_SHORTCUT"):
+            for main, other in ((0, 1), (1, 0)):
+                is_pass = len(self.net[other]) == 1 and isinstance(self.net[other][0], nn.Identity)
+                plan = self._plan[main]
+                if not (is_pass and plan and plan[-1][0] == "norm_neuron" and plan[-1][2] == 2):
+                    continue
+                holder = self.net[main][plan[-1][1] + 1]
+                if isinstance(_neuron_cell(holder), LIFCell) and not isinstance(holder, StateStorage):
+                    self._fused_shortcut = (main, other)
+                    break
         self._pass_offset: Optional[int] = None
         if self.merge == "dense":
             for k, branch in enumerate(self.net):
@@ -160,6 +174,7 @@ class BlockGen(nn.Module):
                 branch_dest = dest
             else:
                 branch_dest = None  # residual: branches are summed, only the sum is placed
+            fuse_here = self._fused_shortcut is not None and self._fused_shortcut[0] == b
             Y = inputs[b]
             pending = None  # promise prepared for the next step (a Dense block with a Pass branch)
             for k, (kind, idx, span) in enumerate(plan):
@@ -183,7 +198,11 @@ class BlockGen(nn.Module):
                     old = branch_state[idx + 1]
                     # LI+Tanh keeps its own output for the backward pass and wants it dense: place by copy
                     direct = step_dest if neuron != _hip.NEURON_LI_TANH else None
-                    Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct)
+                    shortcut = None
+                    if fuse_here and last:  # the block's merged output: LIF(...) + shortcut, placed at `dest`
+                        direct, shortcut = dest, inputs[self._fused_shortcut[1]]
+                    Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct,
+                                              addend=shortcut)
                     if isinstance(holder, StateStorage):
                         holder.record(old, Y, new)
                     branch_state[idx + 1] = new
@@ -203,7 +222,9 @@ class BlockGen(nn.Module):
                 Y = HF.place(Y, branch_dest)
             out.append(Y)
             out_state.append(branch_state)
-        if self.merge == "residual":
+        if self.merge == "residual" and self._fused_shortcut is not None:
+            merged = out[self._fused_shortcut[0]]
+        elif self.merge == "residual":
             merged = HF.sum_tensors(out, dest=dest)
         elif self.merge == "dense":
             merged = HF.assemble_channels(promise, out) if zero_copy else HF.concat_channels(out)

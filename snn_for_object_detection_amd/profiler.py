@@ -48,10 +48,10 @@ def work_of(name: str, a):
         byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
         return _conv_label(name, a), flops, byts
     if name == "snn_affine_neuron_fwd":
-        neuron, T, M, C = a[0], a[12], a[13], a[14]
-        save = a[11] is not None
+        neuron, T, M, C = a[0], a[14], a[15], a[16]
+        tensors = 2 + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)  # + vdec, + fused shortcut
         elems = float(T) * M * C
-        return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * (3 if save else 2)
+        return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * tensors
     if name == "snn_affine_neuron_bwd":
         neuron, T, M, C = a[0], a[15], a[16], a[17]
         elems = float(T) * M * C

@@ -24,7 +24,7 @@ def shape_of(name, a):
     if name.startswith("snn_conv2d"):
         return f"N{a[5]} {a[6]}x{a[7]} {a[8]}->{a[11]} k{a[12]} s{a[14]}"
     if name == "snn_affine_neuron_fwd":
-        return f"n{a[0]} T{a[12]} M{a[13]} C{a[14]}"
+        return f"n{a[0]} T{a[14]} M{a[15]} C{a[16]}{' +shortcut' if a[9] is not None else ''}"
     if name == "snn_affine_neuron_bwd":
         return f"n{a[0]} T{a[15]} M{a[16]} C{a[17]}"
     if name == "snn_add":

@@ -27,7 +27,7 @@ for (T, B, H, W, C) in [(32, 5, 120, 152, 64), (32, 5, 120, 152, 32), (32, 5, 60
 
     def fwd():
         _hip.call("snn_affine_neuron_fwd", 1, y.data_ptr(), C, alpha.data_ptr(), beta.data_ptr(), None, None,
-                  out.data_ptr(), C, vT.data_ptr(), iT.data_ptr(), vdec.data_ptr(), T, M, C, p, st)
+                  out.data_ptr(), C, None, 0, vT.data_ptr(), iT.data_ptr(), vdec.data_ptr(), T, M, C, p, st)
 
     def bwd(with_sums):
         _hip.call("snn_affine_neuron_bwd", 1, go.data_ptr(), C, vdec.data_ptr(), y.data_ptr(), C, None, None, None, None,

@@ -25,7 +25,7 @@ for _ in range(3):
     if op == "fwd":
         _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, st)
     elif op == "dgrad":
-        _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, st)
+        _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, st)
     else:
         _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 0, ws.data_ptr(), splitk, st)
 torch.cuda.synchronize()
