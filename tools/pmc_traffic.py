@@ -20,9 +20,11 @@ def family(name: str) -> str:
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     m = re.match(r"([A-Za-z0-9_:]+)", name)
     base = m.group(1) if m else name
-    if base == "k_conv_gather":
+    if base == "k_conv_gather":  # <BN, WM, WN, DGRAD, VEC, ...>: the first five arguments, as profiler.py labels them
         t = re.search(r"k_conv_gather<([^>]*)>", name)
-        return f"k_conv_gather<{t.group(1)}>" if t else base
+        return f"k_conv_gather<{', '.join(a.strip() for a in t.group(1).split(',')[:5])}>" if t else base
+    if base.startswith("k_conv_wgrad") or base == "k_wgrad_reduce":
+        return "k_conv_wgrad"  # one snn_conv2d_wgrad call = one tile kernel (any variant) + its ordered reduce
     return base
 
 
@@ -34,7 +36,7 @@ def load(path, counter):
                 continue
             k = family(r["Kernel_Name"])
             per[k][0] += float(r["Counter_Value"])
-            per[k][1] += 1
+            per[k][1] += 0 if "k_wgrad_reduce" in r["Kernel_Name"] else 1  # the reduce belongs to its tile kernel's call
     return per
 
 
