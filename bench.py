@@ -93,8 +93,8 @@ def cpu_baseline(sample_T, sample_B, H, W, num_classes, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=5, help="samples per GPU")
     ap.add_argument("--timesteps", type=int, default=32)
     ap.add_argument("--height", type=int, default=GEN1_H)

@@ -7,6 +7,7 @@
 //
 // Reference semantics: layer_gen.py:211-214 (BatchNorm2d, per-timestep batch statistics),
 // layer_gen.py:232-235 / 252-254 (norse LIFCell / LICell), tiny_yolo.py:39-44 (LI -> Tanh).
+#include <stdlib.h>
 #include "snn_common.h"
 
 namespace {
@@ -137,6 +138,82 @@ __global__ void k_bn_stats_finalize(const double* __restrict__ partial, int chun
     float a = is * g;
     alpha[idx] = a;
     beta[idx] = b - mu * a;
+}
+
+// One launch for the whole statistics second phase of a layer (was: finalize + running update, 27 us of two
+// latency-bound kernels 22 times per step).  One block per channel; 8 lanes share the chunk partials of one
+// (t, c) (each sums every 8th chunk in order, then a fixed xor tree), 32 timesteps per pass; thread 0 applies the T
+// sequential running-stat updates of one reference forward from LDS.  Fixed summation order: deterministic.
+__global__ __launch_bounds__(256) void k_bn_stats_finalize_fused(
+    const double* __restrict__ partial, int chunks, int T, int64_t M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ bias, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int use_running, float* __restrict__ mean, float* __restrict__ invstd,
+    float* __restrict__ alpha, float* __restrict__ beta) {
+    __shared__ float sm_mean[32];
+    __shared__ double sm_var[32];
+    const int c = blockIdx.x;
+    const int sub = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const bool update = !use_running && running_mean && running_var;
+    float rm = 0.f, rv = 0.f;
+    if (update && threadIdx.x == 0) {
+        rm = running_mean[c];
+        rv = running_var[c];
+    }
+    const float g = gamma ? gamma[c] : 1.0f;
+    const float b = bias ? bias[c] : 0.0f;
+    const double mom = (double)momentum;
+    for (int tb = 0; tb < T; tb += 32) {
+        const int t = tb + tl;
+        double s = 0.0, q = 0.0;
+        if (!use_running && t < T) {
+            for (int k = sub; k < chunks; k += 8) {
+                const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
+                s += src[0];
+                q += src[1];
+            }
+        }
+        for (int stride = 4; stride >= 1; stride >>= 1) {
+            s += __shfl_xor(s, stride, 64);
+            q += __shfl_xor(q, stride, 64);
+        }
+        if (sub == 0 && t < T) {
+            const int idx = t * C + c;
+            float mu, is;
+            if (use_running) {
+                mu = running_mean[c];
+                is = 1.0f / sqrtf(running_var[c] + eps);  // ATen eval path: invstd in fp32
+            } else {
+                const double n = (double)M;
+                const double m = s / n;
+                double var = q / n - m * m;
+                if (var < 0.0) var = 0.0;
+                mu = (float)m;
+                is = (float)(1.0 / sqrt(var + (double)eps));
+                sm_mean[tl] = mu;
+                sm_var[tl] = (M > 1) ? var * n / (n - 1.0) : var;
+            }
+            mean[idx] = mu;
+            invstd[idx] = is;
+            const float a = is * g;
+            alpha[idx] = a;
+            beta[idx] = b - mu * a;
+        }
+        if (update) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int nt = T - tb < 32 ? T - tb : 32;
+                for (int k = 0; k < nt; ++k) {
+                    rm = (float)(mom * (double)sm_mean[k] + (1.0 - mom) * (double)rm);
+                    rv = (float)(mom * sm_var[k] + (1.0 - mom) * (double)rv);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (update && threadIdx.x == 0) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
 }
 
 // chunk partials -> sums[t][c][2] (the quantity a SyncBatchNorm exchange all-reduces, config.yaml:76)
@@ -274,7 +351,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 // BatchNorm gradients are bitwise reproducible.  (Channel counts whose per-block group count is not a
 // power of two fall back to LDS float atomics on one shared slab.)
 // ------------------------------------------------------------------------------------------
-constexpr int kBwdNP = 4;
+#ifndef SNN_BWD_NP
+#define SNN_BWD_NP 4
+#endif
+constexpr int kBwdNP = SNN_BWD_NP;
 constexpr int kWaves = kThreads / 64;
 
 struct BwdPlan {
@@ -316,6 +396,7 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     // kBwdNP-row groups left e.g. 713 groups on 512 blocks: 2 rounds for 1.4 rounds of work.)
     const int64_t rows = snn_ceil_div(M, (int64_t)P);
     int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;  // 64 KiB of LDS per block -> 2 blocks per CU
+    if (const char* force = getenv("SNN_BWD_CAP")) cap = atoi(force) > 0 ? atoi(force) : cap;  // tuning aid
     cap = cap / pl.gy;
     if (cap < 1) cap = 1;
     const int64_t rpb = snn_ceil_div(rows, rows < cap ? rows : cap);
@@ -518,8 +599,9 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     }
     if (MODE != 0) {
         __syncthreads();
-        // sums[bx][t][c][2]
-        double* dst = sums + (int64_t)blockIdx.x * T * C * 2;
+        // sums[bx][t][c][2], stored as fp32 (the block sums ARE fp32; doubles would only double the bytes the
+        // finalize kernel reads back: up to 512 x T x C x 2 values per layer)
+        float* dst = reinterpret_cast<float*>(sums) + (int64_t)blockIdx.x * T * C * 2;
         const int c_lo = blockIdx.y * cb;
         for (int k = tid; k < T * cb; k += kThreads) {
             int t = k / cb, cl = k % cb;
@@ -535,33 +617,33 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     a = red[k * 2 + 0];
                     b = red[k * 2 + 1];
                 }
-                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = (double)a;
-                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = (double)b;
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = a;
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = b;
             }
         }
     }
 }
 
 // reduce block partials -> raw[t][c] = (sum gx, sum gx*y).  32 lanes per (t,c): lane k sums blocks k, k+32, ...
-// then a fixed xor tree combines the lanes.  `raw` may be the partial buffer itself (block 0's slot).
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict__ sums, int gx_blocks, int T, int C,
+// then a fixed xor tree combines the lanes.  `raw` must not alias the partial buffer (fp32 partials, fp64 result).
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict__ sums_, int gx_blocks, int T, int C,
                                                        double* __restrict__ raw) {
+    const float* __restrict__ sums = reinterpret_cast<const float*>(sums_);
     const int sub = threadIdx.x & 31;
     const int idx = blockIdx.x * (blockDim.x / 32) + (threadIdx.x >> 5);
     const bool live = idx < T * C;
     double s1 = 0.0, sy = 0.0;
     if (live) {
         for (int b = sub; b < gx_blocks; b += 32) {
-            const double* src = sums + ((int64_t)b * T * C + idx) * 2;
-            s1 += src[0];
-            sy += src[1];
+            const float2 v = *reinterpret_cast<const float2*>(sums + ((int64_t)b * T * C + idx) * 2);
+            s1 += (double)v.x;
+            sy += (double)v.y;
         }
     }
     for (int stride = 16; stride >= 1; stride >>= 1) {
         s1 += __shfl_xor(s1, stride, 64);
         sy += __shfl_xor(sy, stride, 64);
     }
-    __syncthreads();  // every partial of this block's (t,c) pairs has been read before slot 0 is rewritten
     if (!live || sub != 0) return;
     raw[(int64_t)idx * 2 + 0] = s1;
     raw[(int64_t)idx * 2 + 1] = sy;
@@ -601,6 +683,64 @@ __global__ void k_bn_bwd_params(const double* __restrict__ sums, int T, int C, f
     }
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
     if (dbias) dbias[c] = accumulate ? dbias[c] + (float)db : (float)db;
+}
+
+// One launch for the BatchNorm-backward second phase of a layer (was: reduce + coefficients + parameter gradients).
+// One block per channel; 32 lanes share the block partials of one (t, c) (lane k sums blocks k, k+32, ... in order,
+// then a fixed xor tree), 32 timesteps per pass (1024 threads); thread 0 adds the per-timestep parameter sums in t order.
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize_fused(
+    const double* __restrict__ sums_, int gx_blocks, int T, int64_t M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coefA,
+    float* __restrict__ coefB, float* __restrict__ coefC, float* __restrict__ dgamma, float* __restrict__ dbias,
+    int accumulate) {
+    const float* __restrict__ sums = reinterpret_cast<const float*>(sums_);  // fp32 block partials
+    __shared__ double sm_b[32], sm_g[32];
+    const int c = blockIdx.x;
+    const int sub = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    double dg = 0.0, db = 0.0;
+    const double gam = (double)(gamma ? gamma[c] : 1.0f);
+    for (int tb = 0; tb < T; tb += 32) {
+        const int t = tb + tl;
+        const int idx = t * C + c;
+        double s1 = 0.0, sy = 0.0;
+        if (t < T) {
+#pragma unroll 4
+            for (int bk = sub; bk < gx_blocks; bk += 32) {
+                const float2 v = *reinterpret_cast<const float2*>(sums + ((int64_t)bk * T * C + idx) * 2);
+                s1 += (double)v.x;
+                sy += (double)v.y;
+            }
+        }
+        for (int stride = 16; stride >= 1; stride >>= 1) {
+            s1 += __shfl_xor(s1, stride, 64);
+            sy += __shfl_xor(sy, stride, 64);
+        }
+        if (sub == 0 && t < T) {
+            const double mu = (double)mean[idx], is = (double)invstd[idx];
+            const double s2 = is * (sy - mu * s1);  // sum gx * xhat
+            const double n = (double)M;
+            const double a = gam * is;
+            const double m1 = s1 / n, m2 = s2 / n;
+            coefA[idx] = (float)a;
+            coefB[idx] = (float)(-a * is * m2);
+            coefC[idx] = (float)(-a * m1 + a * is * mu * m2);
+            sm_b[tl] = s1;
+            sm_g[tl] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nt = T - tb < 32 ? T - tb : 32;
+            for (int k = 0; k < nt; ++k) {
+                db += sm_b[k];
+                dg += sm_g[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+        if (dbias) dbias[c] = accumulate ? dbias[c] + (float)db : (float)db;
+    }
 }
 
 template <int VEC>
@@ -671,18 +811,10 @@ extern "C" int snn_bn_stats_finalize(const double* partial, int T, int64_t M, in
     SNN_REQUIRE(use_running ? (running_mean && running_var) : (partial != nullptr),
                 "snn_bn_stats_finalize: missing statistics source");
     StatsPlan pl = stats_plan(T, M, C);
-    double* var_unbiased =
-        use_running ? nullptr : const_cast<double*>(partial) + (size_t)T * pl.chunks * C * 2;
-    int n = T * C;
-    hipLaunchKernelGGL(k_bn_stats_finalize, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
-                       pl.chunks, T, M, C, gamma, bias, eps, running_mean, running_var, use_running, mean, invstd,
-                       alpha, beta, var_unbiased);
+    hipLaunchKernelGGL(k_bn_stats_finalize_fused, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, pl.chunks, T, M,
+                       C, gamma, bias, eps, momentum, running_mean, running_var, use_running, mean, invstd, alpha,
+                       beta);
     SNN_CHECK_LAUNCH("snn_bn_stats_finalize");
-    if (!use_running && running_mean && running_var) {
-        hipLaunchKernelGGL(k_bn_running_update, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean,
-                           var_unbiased, T, C, momentum, running_mean, running_var);
-        SNN_CHECK_LAUNCH("snn_bn_running_update");
-    }
     return 0;
 }
 
@@ -828,6 +960,7 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
 
 extern "C" int snn_bn_bwd_reduce(const double* sums, int T, int64_t M, int C, double* raw, void* stream) {
     SNN_REQUIRE(sums && raw && T > 0 && M > 0 && C > 0, "snn_bn_bwd_reduce: bad arguments");
+    SNN_REQUIRE(sums != raw, "snn_bn_bwd_reduce: raw must not alias the partial sums");
     BwdPlan pl = bwd_plan(T, M, C, true);
     int n = T * C;
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, C, raw);
@@ -859,10 +992,12 @@ extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const 
                                    const float* invstd, float* coefA, float* coefB, float* coefC, float* dgamma,
                                    float* dbias, int accumulate, void* stream) {
     SNN_REQUIRE(sums && mean && invstd && coefA && coefB && coefC, "snn_bn_bwd_finalize: null pointer");
-    int rc = snn_bn_bwd_reduce(sums, T, M, C, sums, stream);
-    if (rc) return rc;
-    return snn_bn_bwd_coef(sums, sums, sums, T, M, C, gamma, mean, invstd, coefA, coefB, coefC, dgamma, dbias,
-                           accumulate, stream);
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_bwd_finalize: bad shape");
+    BwdPlan pl = bwd_plan(T, M, C, true);
+    hipLaunchKernelGGL(k_bn_bwd_finalize_fused, dim3(C), dim3(1024), 0, (hipStream_t)stream, sums, pl.gx, T, M, C, gamma,
+                       mean, invstd, coefA, coefB, coefC, dgamma, dbias, accumulate);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_finalize");
+    return 0;
 }
 
 extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, const float* coefA, const float* coefB,

@@ -12,7 +12,8 @@ from snn_for_object_detection_amd.functional import neuron_params  # noqa: E402
 _hip.load()
 dev, st = torch.device("cuda"), torch.cuda.current_stream().cuda_stream
 p = neuron_params()
-for (T, B, H, W, C) in [(32, 5, 120, 152, 64), (32, 5, 120, 152, 32), (32, 5, 60, 76, 128), (32, 5, 30, 38, 256)]:
+for (T, B, H, W, C) in [(32, 5, 120, 152, 64), (32, 5, 120, 152, 32), (32, 5, 60, 76, 128), (32, 5, 60, 76, 64),
+                        (32, 5, 30, 38, 256), (32, 5, 30, 38, 128), (32, 5, 15, 19, 128), (32, 5, 8, 10, 128)]:
     M = B * H * W
     y = torch.randn(T, M, C, device=dev)
     go = torch.randn(T, M, C, device=dev)
