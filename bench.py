@@ -36,7 +36,8 @@ PEAK_HBM_GBS = 8000.0
 def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3) or 6 (bf16x6) dense
     bf16 MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
-    backward = kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
+    backward = (kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
+                or kernel.endswith(", true>"))  # k_conv_direct3<BN, WM, WN, DGRAD>
     prec = bwd_prec if backward else fwd_prec
     if prec == "bf16x3":
         return PEAK_BF16_MATRIX_TFLOPS / 3.0, "bf16 dense MFMA / 3 products"

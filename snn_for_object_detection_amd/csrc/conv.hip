@@ -66,6 +66,7 @@ struct ConvGeom {
     unsigned magic_ic, magic_kw;
     int out_vec;  // output (and addend) rows may be stored 16 bytes per lane
     int nimg;     // images in the gathered tensor (FAST loader: extent of its buffer resource)
+    int mtiles, mtiles_per_xcd, ntiles;  // XCD-aware tile order (see k_conv_gather)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -120,8 +121,18 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane_id & 31, h = lane_id >> 5;
 
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2): ids
+    // L, L+8, L+16, ... run on one XCD.  XCD x gets the x-th CONTIGUOUS eighth of the pixel tiles (and all channel
+    // tiles of a pixel tile back to back), so the blocks resident together on an XCD cover neighbouring image rows
+    // and the 3x3 taps that reach into the rows above / below hit that XCD's L2.  With the plain order every XCD
+    // held scattered 128-pixel segments and re-fetched the neighbouring rows from HBM (PMC: the 32-channel 3x3
+    // data gradient read its input 5x).
+    const int bid_xcd = blockIdx.x & 7, bid_q = blockIdx.x >> 3;
+    const int bid_n = bid_q % g.ntiles;
+    const int64_t bid_m = (int64_t)bid_xcd * g.mtiles_per_xcd + bid_q / g.ntiles;
+    if (bid_m >= g.mtiles) return;  // padding block of the last XCD share (whole block, before any barrier)
+    const int64_t m0 = bid_m * BM;
+    const int n0 = bid_n * BN;
 
     // ---- per-thread loader geometry: rows lr + 32*j, k offset kq
     // Rows are permuted so that the two rows written by one 16-lane LDS store group lie 4 rows (320 B) apart: with
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             STAMP(5);
         }
 #ifdef SNN_STAMP
-        if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+        if (tid == 0 && bid_n == 0 && blockIdx.x < 2048) {
             st_acc[6] = __builtin_readcyclecounter() - st_begin;
             st_acc[7] = st_begin;
             for (int i = 0; i < 8; ++i) g_stamps[blockIdx.x * 8 + i] = st_acc[i];
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         __syncthreads();
     }
 #ifdef SNN_STAMP
-    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) {
+    if (tid == 0 && bid_n == 0 && blockIdx.x < 2048) {
         g_stamps2[blockIdx.x * 4 + 0] = st_kernel_begin;
         g_stamps2[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1347,7 +1358,11 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
                  (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
     do {                                                                                                    \
-        dim3 grid((unsigned)gm, (unsigned)snn_ceil_div(g.OC, BN_));                                         \
+        gg.mtiles = (int)gm;                                                                                \
+        gg.mtiles_per_xcd = (int)snn_ceil_div(gm, 8);                                                       \
+        gg.ntiles = (int)snn_ceil_div(g.OC, BN_);                                                           \
+        SNN_REQUIRE((int64_t)gg.mtiles_per_xcd * 8 * gg.ntiles <= 0x7fffffffLL, "%s: grid too large", name); \
+        dim3 grid((unsigned)(gg.mtiles_per_xcd * 8 * gg.ntiles));                                           \
         if (fast)                                                                                           \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
@@ -1362,6 +1377,382 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     else if (g.OC <= 64) SNN_CONV_LAUNCH(64, 2, 2);
     else SNN_CONV_LAUNCH(128, 2, 2);
 #undef SNN_CONV_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snn_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ direct 3x3
+// Direct 3x3 / stride 1 / pad 1 convolution for layers with <= 64 output channels (the 32- and 64-channel
+// bottleneck convolutions of the two high-resolution stages).  In the implicit-GEMM kernel above every input element
+// is fetched and split into its bf16 pieces once PER TAP (9x), and with so few output channels that conversion work,
+// not the MFMAs, sets the speed.  Here a block owns an 8 x 16 patch of output pixels: per 32-channel chunk the
+// 10 x 18 input halo is fetched and converted ONCE into LDS and all nine taps read it at shifted row offsets; only
+// the weight tiles stream through the register pipeline (convert in the MFMA shadow, as in k_conv_gather).
+// FLIP selects the data-gradient form: out = conv(dy, w^T with the taps mirrored).
+struct DirectGeom {
+    int IH, IW, IC, OC;     // gathered tensor / produced channels (output is IH x IW as well)
+    int64_t ldi, ldo;
+    int nimg, pht, pwt;     // patches per image column / row
+    int tiles, tiles_per_xcd;
+    int KtotFull;           // 9 * IC
+    int out_vec;
+};
+constexpr int DPH = 8, DPW = 16, DHW = DPW + 2, DHALO = (DPH + 2) * DHW;  // 180 halo pixels
+constexpr int DHROWS = (DHALO + 7) / 8 * 8;                               // 184 LDS rows (whole groups of 8)
+
+template <int BN, int WM, int WN, int SPLIT, int TPS, bool FLIP>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __restrict__ in, const float* __restrict__ wk,
+                                                              float* __restrict__ out, DirectGeom g,
+                                                              const float* __restrict__ addend, int64_t ld_add,
+                                                              const float* __restrict__ addend2, int64_t ld_add2) {
+    static_assert(WM * WN == 4 && (SPLIT == 2 || SPLIT == 3) && (TPS == 1 || TPS == 3), "configuration");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NP = SPLIT, NPROD = SPLIT == 3 ? 6 : 3;
+    constexpr int SPC = 9 / TPS;                 // stages per 32-channel chunk
+    constexpr int BJ = TPS * BN / 32;            // weight f32x4 per thread and stage
+    constexpr int AJ = (DHROWS * 8 + kThreads - 1) / kThreads;  // halo f32x4 per thread and chunk (6)
+    constexpr int A_BYTES = NP * DHROWS * LDB * 2, B_BYTES = NP * TPS * BN * LDB * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+    __bf16* Ai[3];
+    __bf16* Bi[3];
+#pragma unroll
+    for (int pz = 0; pz < NP; ++pz) {  // piece images: 0 hi, 1 lo, 2 mid
+        Ai[pz] = reinterpret_cast<__bf16*>(smem) + pz * DHROWS * LDB;
+        Bi[pz] = reinterpret_cast<__bf16*>(smem + A_BYTES) + pz * TPS * BN * LDB;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane_id = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane_id & 31, h = lane_id >> 5;
+
+    // ---- persistent blocks, XCD-aware: XCD x owns the x-th contiguous eighth of the patches; its blocks (ids x, x+8,
+    // ...) walk that range with stride "blocks per XCD".  A 32-channel layer has only 3 stages per patch, so the
+    // per-patch prologue (first halo + weights with their full load latency) and the epilogue are overlapped with
+    // the neighbouring patches instead of being paid per block.
+    const int nbx = gridDim.x >> 3;
+    const int t_lo = (blockIdx.x & 7) * g.tiles_per_xcd;
+    const int t_hi = t_lo + g.tiles_per_xcd < g.tiles ? t_lo + g.tiles_per_xcd : g.tiles;
+    int tile = t_lo + (blockIdx.x >> 3);
+    if (tile >= t_hi) return;
+    const int ppi = g.pht * g.pwt;
+    const int64_t ipix = (int64_t)g.IH * g.IW;
+    int img = 0, oy0 = 0, ox0 = 0;
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, g.OC * g.KtotFull * 4, 0x00020000);
+
+    // ---- loader geometry.  Row permutation inside groups of 8 (rows R, R+1 -> R', R'+4): conflict-free LDS stores.
+    const int kq = (tid & 7) * 4;
+    int a_off[AJ], a_row[AJ];  // byte offset of (halo pixel, channel kq) in the image (-1: outside), LDS row (-1: none)
+    int a_hy[AJ], a_hx[AJ];    // halo coordinates of the thread's rows (tile independent)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int rp = (tid >> 3) + 32 * j;
+        const int hrow = (rp & ~7) | ((rp >> 1) & 3) | ((rp & 1) << 2);
+        a_hy[j] = hrow / DHW;
+        a_hx[j] = hrow - a_hy[j] * DHW;
+        a_row[j] = rp < DHROWS ? hrow : -1;
+        if (hrow >= DHALO) a_hy[j] = -0x10000;  // never inside an image
+    }
+    auto setup_tile = [&](int t) {  // t is block-uniform
+        img = t / ppi;
+        const int prem = t - img * ppi;
+        const int ty = prem / g.pwt, tx = prem - ty * g.pwt;
+        oy0 = ty * DPH;
+        ox0 = tx * DPW;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)img * ipix * g.ldi), 0,
+                                                 (int)(((ipix - 1) * g.ldi + g.IC) * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int iy = oy0 - 1 + a_hy[j], ix = ox0 - 1 + a_hx[j];
+            const bool inside = a_row[j] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            a_off[j] = inside ? ((iy * g.IW + ix) * (int)g.ldi + kq) * 4 : -1;
+        }
+    };
+    const int lrr = tid >> 3;
+    const int lr = ((lrr >> 1) & 3) + 4 * (lrr & 1) + 8 * (lrr >> 3);
+    unsigned b_off[BJ];  // byte offset of (weight row, column kq); >= 2^31 for rows past OC
+    int b_tp[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int idx = j * 32 + lr;
+        b_tp[j] = idx / BN;
+        const int n = idx - b_tp[j] * BN;
+        b_off[j] = n < g.OC ? (unsigned)(n * g.KtotFull + kq) * 4u : 0x80000000u;
+    }
+
+    f32x4 ra[AJ], rb[BJ];
+    bf16x4 pb[BJ][NP];
+    auto load_a = [&](int chunk) {  // chunk is block-uniform
+        const int c4 = chunk * BK * 4;
+        const bool live = chunk * BK < g.IC;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int voff = (live && a_off[j] >= 0) ? a_off[j] + c4 : -1;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
+        }
+    };
+    auto load_b = [&](int stage) {  // stage = chunk * SPC + tap group (block-uniform)
+        const int chunk = stage / SPC, tg = stage - chunk * SPC;
+        const bool live = chunk * BK < g.IC;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int tap = tg * TPS + b_tp[j];
+            const int wtap = FLIP ? 8 - tap : tap;
+            const unsigned col = (unsigned)(wtap * g.IC + chunk * BK) * 4u;
+            const int voff = live ? (int)(b_off[j] + col) : -1;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0));
+        }
+    };
+    auto convert = [&](const f32x4& v, bf16x4* o) {  // o[0] hi, o[1] lo, o[2] mid
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            f32x2 rest = {v[e], v[e + 1]};
+            bf16x2 p = __builtin_convertvector(rest, bf16x2);
+            unsigned bits = __builtin_bit_cast(unsigned, p);
+            o[0][e] = p[0]; o[0][e + 1] = p[1];
+            rest[0] -= __builtin_bit_cast(float, bits << 16);
+            rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+            if (SPLIT == 3) {
+                p = __builtin_convertvector(rest, bf16x2);
+                bits = __builtin_bit_cast(unsigned, p);
+                o[2][e] = p[0]; o[2][e + 1] = p[1];
+                rest[0] -= __builtin_bit_cast(float, bits << 16);
+                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+            }
+            p = __builtin_convertvector(rest, bf16x2);
+            o[1][e] = p[0]; o[1][e + 1] = p[1];
+        }
+    };
+    auto write_a = [&]() {  // convert + store the halo of the next chunk (once per 9 taps: not worth hiding)
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            if (a_row[j] < 0) continue;
+            bf16x4 o[3];
+            convert(ra[j], o);
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz) *reinterpret_cast<bf16x4*>(&Ai[pz][a_row[j] * LDB + kq]) = o[pz];
+        }
+    };
+    auto write_b = [&]() {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz)
+                *reinterpret_cast<bf16x4*>(&Bi[pz][(j * 32 + lr) * LDB + kq]) = pb[j][pz];
+    };
+
+    // A-fragment row of lane r in M-tile i: patch pixel p = (wm*TM + i)*32 + r -> halo pixel (p/16, p%16) + tap shift
+    int a_frag[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (wm * TM + i) * 32 + r;
+        a_frag[i] = ((p >> 4) * DHW + (p & 15)) * LDB + 8 * h;
+    }
+
+    f32x16 acc[TM][TN];
+    struct Frag {
+        bf16x8 a[TM][NP], b[TN][NP];
+    };
+    auto read_frag = [&](Frag& f, int tp, int kh, int kw, int ks) {
+        const int toff = (kh * DHW + kw) * LDB + ks * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz) f.a[i][pz] = *reinterpret_cast<const bf16x8*>(&Ai[pz][a_frag[i] + toff]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pz = 0; pz < NP; ++pz)
+                f.b[j][pz] = *reinterpret_cast<const bf16x8*>(
+                    &Bi[pz][(tp * BN + (wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h]);
+    };
+    auto mfma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {  // small terms first; pieces: 0 hi, 1 lo, 2 mid
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
+                if (SPLIT == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int nchunks = g.IC / BK;
+    const int nstages = nchunks * SPC;
+    constexpr int NM = TM * TN * NPROD;                      // MFMAs per (tap, k16) group
+    constexpr int NGRP = TPS * 2;                            // groups per stage
+    constexpr int CONV_OPS = SPLIT == 3 ? 24 : 14;
+    constexpr int VPG = (BJ * CONV_OPS + NGRP * NM - 1) / (NGRP * NM);
+    setup_tile(tile);
+    load_a(0);
+    load_b(0);
+#pragma unroll 1
+    for (;;) {
+        // ---- patch prologue: halo of chunk 0 and weights of stage 0 into LDS; the next ones into registers
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        write_a();
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j]);
+        write_b();
+        load_a(1);
+        load_b(1);
+        __syncthreads();
+        int chunk = 0, tg = 0;
+    #pragma unroll 1
+        for (int s = 0; s < nstages; ++s) {
+            // fragment reads run one (tap, k16) group ahead of the MFMAs that consume them
+            Frag fr[2];
+            {
+                const int tap0 = tg * TPS;
+                read_frag(fr[0], 0, TPS == 3 ? tg : tap0 / 3, TPS == 3 ? 0 : tap0 - (tap0 / 3) * 3, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * NP, 0);
+#pragma unroll
+            for (int gq = 0; gq < NGRP; ++gq) {
+                if (gq + 1 < NGRP) {
+                    const int tp = (gq + 1) >> 1, ks = (gq + 1) & 1;
+                    const int tap = tg * TPS + tp;
+                    read_frag(fr[(gq + 1) & 1], tp, TPS == 3 ? tg : tap / 3, TPS == 3 ? tp : tap - (tap / 3) * 3, ks);
+                }
+                mfma_frag(fr[gq & 1]);
+                if (gq == 0) {
+#pragma unroll
+                    for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j]);  // weights of stage s+1, in the MFMA shadow
+                }
+            }
+            // schedule shape: [reads of group g+1] then the MFMAs of group g, each followed by its share of the VALU
+#pragma unroll
+            for (int gq = 0; gq < NGRP; ++gq) {
+                __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN) * NP, 0);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(s + 2);
+            __syncthreads();
+            write_b();
+            if (tg == SPC - 1) {  // the next stage starts a new chunk: replace the halo, fetch the one after
+                write_a();
+                load_a(chunk + 2);
+                ++chunk;
+                tg = 0;
+            } else {
+                ++tg;
+            }
+            __syncthreads();
+        }
+        // ---- the next patch's first halo / weights are fetched while this patch's results are stored
+        const int e_img = img, e_oy0 = oy0, e_ox0 = ox0;
+        tile += nbx;
+        const bool more = tile < t_hi;
+        if (more) {
+            setup_tile(tile);
+            load_a(0);
+            load_b(0);
+        }
+        // ---- epilogue: accumulators -> LDS (per wave) -> 16-byte stores with up to two fused addends
+        constexpr int EW = TN * 32 + 4, LPR = TN * 8, RPP = 64 / LPR;
+        static_assert(4 * 32 * EW * 4 <= A_BYTES + B_BYTES, "epilogue staging does not fit");
+        float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
+        const bool ovec = g.out_vec != 0;
+    #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+            for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = acc[i][j][e];
+            __syncthreads();
+    #pragma unroll
+            for (int pass = 0; pass < 32 / RPP; ++pass) {
+                const int row = pass * RPP + lane_id / LPR;
+                const int c4 = (lane_id % LPR) * 4;
+                const int p = (wm * TM + i) * 32 + row;
+                const int oy = e_oy0 + (p >> 4), ox = e_ox0 + (p & 15);
+                const int n = wn * TN * 32 + c4;
+                if (oy >= g.IH || ox >= g.IW || n >= g.OC) continue;
+                const int64_t pix = ((int64_t)e_img * g.IH + oy) * g.IW + ox;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
+                float* dst = out + pix * g.ldo + n;
+                if (ovec && n + 3 < g.OC) {
+                    if (addend) v += *reinterpret_cast<const f32x4*>(addend + pix * ld_add + n);
+                    if (addend2) v += *reinterpret_cast<const f32x4*>(addend2 + pix * ld_add2 + n);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < g.OC) {
+                            float o = v[q];
+                            if (addend) o += addend[pix * ld_add + n + q];
+                            if (addend2) o += addend2[pix * ld_add2 + n + q];
+                            dst[q] = o;
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        if (!more) break;
+    }
+}
+
+// returns -1 when the shape is not covered (caller falls back to the implicit-GEMM kernel)
+template <bool FLIP>
+static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* out, int64_t ldo, int64_t N, int H,
+                          int W, int IC, int OC, int split, const float* addend, int64_t ld_add,
+                          const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
+    static const bool off = getenv("SNN_CONV_NO_DIRECT") != nullptr;  // tuning / bisecting aid
+    // measured: a win (12-15 %) for <= 32 output channels; at 64 the implicit-GEMM kernel is as fast or faster
+    // (both are bound by LDS operand traffic there), so it stays the default; SNN_CONV_DIRECT_MAX_OC=64 to compare
+    static const int max_oc = getenv("SNN_CONV_DIRECT_MAX_OC") ? atoi(getenv("SNN_CONV_DIRECT_MAX_OC")) : 32;
+    if (off || (split != 2 && split != 3) || IC % BK != 0 || OC > max_oc || OC > 64 || OC % 4 != 0) return -1;
+    if (ldi % 4 != 0 || !aligned16(in) || !aligned16(wk)) return -1;
+    if ((int64_t)H * W * ldi * 4 >= 0x7fffffffLL || (int64_t)OC * 9 * IC * 4 >= 0x7fffffffLL) return -1;
+    DirectGeom g;
+    g.IH = H; g.IW = W; g.IC = IC; g.OC = OC;
+    g.ldi = ldi; g.ldo = ldo;
+    g.nimg = (int)N;
+    g.pht = (H + DPH - 1) / DPH;
+    g.pwt = (W + DPW - 1) / DPW;
+    const int64_t tiles = N * g.pht * g.pwt;
+    if (tiles > 0x0fffffffLL) return -1;
+    g.tiles = (int)tiles;
+    g.tiles_per_xcd = (int)snn_ceil_div(tiles, 8);
+    g.KtotFull = 9 * IC;
+    g.out_vec = (ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
+                (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
+    // persistent: at most (CUs per XCD) x (resident blocks per CU) blocks per XCD
+    const int resident = (OC <= 32 && split == 2) ? 3 : 2;
+    int nbx = (SNN_NUM_CU / 8) * resident;
+    if (nbx > g.tiles_per_xcd) nbx = g.tiles_per_xcd;
+    dim3 grid((unsigned)(nbx * 8));
+#define SNN_DIRECT_LAUNCH(BN_, WM_, WN_, SPLIT_, TPS_)                                                            \
+    hipLaunchKernelGGL((k_conv_direct3<BN_, WM_, WN_, SPLIT_, TPS_, FLIP>), grid, dim3(kThreads), 0, st, in, wk, out, \
+                       g, addend, ld_add, addend2, ld_add2)
+    if (OC <= 32) {
+        if (split == 3) SNN_DIRECT_LAUNCH(32, 4, 1, 3, 3);
+        else SNN_DIRECT_LAUNCH(32, 4, 1, 2, 3);
+    } else {
+        if (split == 3) SNN_DIRECT_LAUNCH(64, 2, 2, 3, 1);
+        else SNN_DIRECT_LAUNCH(64, 2, 2, 2, 3);
+    }
+#undef SNN_DIRECT_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snn_set_error("%s: launch failed: %s", name, hipGetErrorString(e));
@@ -1414,6 +1805,11 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+        const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, g_forward_split, addend, ld_addend,
+                                             nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+        if (rc >= 0) return rc;
+    }
     if (g_forward_split == 3)
         return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
@@ -1438,6 +1834,11 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     const bool split = g_backward_split != 0;
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {  // dx = conv(dy, mirrored taps of w^T)
+        const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
+                                            ld_addend, addend2, ld_addend2, (hipStream_t)stream, "snn_conv2d_dgrad");
+        if (rc >= 0) return rc;
+    }
     // one launch per stride phase: each class multiplies only the taps that can reach it
     for (int ph = 0; ph < stride && ph < H; ++ph)
         for (int pw = 0; pw < stride && pw < W; ++pw) {

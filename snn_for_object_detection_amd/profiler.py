@@ -26,6 +26,8 @@ def _conv_label(name: str, a) -> str:
     dgrad = name == "snn_conv2d_dgrad"
     cin, cout = a[8], a[11]
     oc, ic = (cin, cout) if dgrad else (cout, cin)
+    if a[12] == 3 and a[13] == 3 and a[14] == 1 and a[15] == 1 and oc <= 32 and oc % 4 == 0 and ic % 32 == 0:
+        return f"k_conv_direct3<32, 4, 1, {'true' if dgrad else 'false'}>"  # halo-resident 3x3 kernel
     if oc <= 32:
         tile = "32, 4, 1"
     elif oc <= 64:
