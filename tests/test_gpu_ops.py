@@ -36,6 +36,11 @@ CONV_CASES = [
     (1, 1, 8, 9, 7, 16, 1, 2),        # k=1 stride 2: three of the four dgrad stride-phase classes have no tap
     (1, 2, 4, 11, 10, 8, 3, 3),       # stride 3
     (2, 1, 128, 15, 19, 256, 3, 2),   # neck downsampling conv shape (odd sizes)
+    # halo-resident direct 3x3 kernel (<= 32 output channels, Cin % 32 == 0), 8x16 patches:
+    (2, 2, 64, 13, 21, 16, 3, 1),     # two 32-channel chunks, partial patches on both edges
+    (1, 3, 32, 8, 16, 8, 3, 1),       # exactly one patch per image, 8 output channels
+    (1, 1, 96, 5, 7, 32, 3, 1),       # image smaller than a patch, three chunks
+    (4, 3, 32, 24, 40, 32, 3, 1),     # 108 patches: the persistent blocks loop over several patches each
 ]
 
 
@@ -72,6 +77,54 @@ def test_conv2d_single_step_and_determinism(HF):
     assert torch.equal(y1, y2) and torch.equal(gx1, gx2) and torch.equal(gw1, gw2)  # bitwise reproducible
     ref = F.conv2d(x.detach().cpu(), w.detach().cpu(), padding=1)
     assert rel_err(y1, ref) < 1e-5
+
+
+def test_dgrad_two_fused_addends(HF, hip_lib):
+    """dx = conv^T(dy) + addend + addend2 in one epilogue (C ABI), addends being channel slices of wider buffers."""
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    for (N, H, W, Cin, Cout, k, s) in [(3, 12, 19, 32, 32, 3, 1), (2, 9, 11, 64, 128, 3, 2), (2, 8, 10, 128, 64, 1, 1)]:
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        dy = torch.randn(N, Ho, Wo, Cout, device="cuda")
+        wt = torch.randn(Cin, k, k, Cout, device="cuda") * 0.05
+        wide1 = torch.randn(N, H, W, Cin + 8, device="cuda")    # addend = channels [4, 4+Cin) of a wider buffer
+        wide2 = torch.randn(N, H, W, 2 * Cin, device="cuda")    # addend2 = channels [Cin, 2Cin)
+        a1, a2 = wide1[..., 4:4 + Cin], wide2[..., Cin:]
+        plain = torch.empty(N, H, W, Cin, device="cuda")
+        fused = torch.empty_like(plain)
+        args = (dy.data_ptr(), Cout, wt.data_ptr())
+        geom = (N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad)
+        _hip.call("snn_conv2d_dgrad", *args, plain.data_ptr(), Cin, *geom, None, 0, None, 0, st)
+        _hip.call("snn_conv2d_dgrad", *args, fused.data_ptr(), Cin, *geom, a1.data_ptr(), Cin + 8, a2.data_ptr(),
+                  2 * Cin, st)
+        assert torch.equal(fused, (plain + a1) + a2)
+        only2 = torch.empty_like(plain)
+        _hip.call("snn_conv2d_dgrad", *args, only2.data_ptr(), Cin, *geom, None, 0, a2.data_ptr(), 2 * Cin, st)
+        assert torch.equal(only2, plain + a2)
+
+
+def test_shortcut_fused_into_lif_store(HF):
+    """affine_neuron(addend=x): out = LIF(BN(y)) + x written by the scan kernel; d out / d x = identity."""
+    torch.manual_seed(12)
+    T, B, C, H, W = 5, 2, 32, 6, 9
+    y = torch.randn(T, B, C, H, W).cuda().requires_grad_()
+    x = torch.randn(T, B, C, H, W).cuda().requires_grad_()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    bn2 = torch.nn.BatchNorm2d(C).cuda().train()
+    from snn_for_object_detection_amd import _hip
+    plain, st_p = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn)
+    fused, st_f = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn2, addend=x)
+    assert torch.equal(fused, plain + x)
+    assert torch.equal(st_f.v, st_p.v) and torch.equal(st_f.i, st_p.i)
+    g = torch.randn_like(fused)
+    gy_p, = torch.autograd.grad(plain, (y,), g, retain_graph=True)
+    gy_f, gx_f = torch.autograd.grad(fused, (y, x), g)
+    assert torch.equal(gy_f, gy_p)
+    assert torch.equal(gx_f, g)
+    with pytest.raises(RuntimeError):
+        HF.affine_neuron(y, _hip.NEURON_LI_TANH, None, bn=bn, addend=x)
 
 
 def _oracle_norm_neuron(y, bn, cell, tanh=False, state=None):
