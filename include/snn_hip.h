@@ -76,6 +76,9 @@ int snn_nchw_to_nhwc(const float* src, float* dst, int64_t N, int C, int H, int 
 int snn_nhwc_to_nchw(const float* src, float* dst, int64_t N, int C, int H, int W, void* stream);
 /* weights [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] (operand of the data-gradient conv) */
 int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* the same for every conv weight of a flat parameter buffer in ONE launch: table[l] = {element offset, Cout, KH*KW, Cin}
+ * (device memory, int64); flat_wt mirrors the offsets of flat_w */
+int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int64_t* table, int n_layers, void* stream);
 
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d(bias=False, padding=int(k/2), stride=s) of layer_gen.py:129-136

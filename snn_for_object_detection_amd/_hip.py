@@ -33,6 +33,7 @@ SIGNATURES = {
     "snn_nchw_to_nhwc": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "snn_nhwc_to_nchw": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "snn_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "snn_weight_transpose_batched": (c_int, [_P, _P, _P, _I, _P]),
     "snn_set_backward_precision": (c_int, [_I]),
     "snn_get_backward_precision": (c_int, []),
     "snn_set_forward_precision": (c_int, [_I]),

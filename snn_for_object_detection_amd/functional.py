@@ -354,6 +354,7 @@ class _Conv2d(Function):
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
                   H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _stream())
         ctx.save_for_backward(x, w_ohwi)
+        ctx.weight_ref = weight if getattr(weight, "_snn_wt", None) is not None else None  # FlatTrainer's cached w^T
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
         ctx.slot = slot
         ctx.acc = acc
@@ -368,8 +369,12 @@ class _Conv2d(Function):
         st = _stream()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
-            _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
+            wref = ctx.weight_ref
+            if wref is not None and wref._snn_wt_version == wref._version:
+                wt = wref._snn_wt  # transposed once per optimiser step for all layers (trainer.FlatTrainer)
+            else:
+                wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
+                _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
             dx = _new_cl((T, B), Cin, H, W, x)
             addend, ld_add, addend2, ld_add2 = None, 0, None, 0
             acc = ctx.acc

@@ -60,6 +60,11 @@ class FlatTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.slots: List[GradSlot] = []
         self.grad_views: List[torch.Tensor] = []
+        # transposed copies [Cin][KH][KW][Cout] of every conv weight (operand of the data-gradient conv), refreshed
+        # by ONE kernel after each optimiser step instead of one launch per layer inside the backward pass
+        self.flat_wt = torch.empty(total_padded, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        self._conv_params: List[torch.nn.Parameter] = []
+        table = []
         off = 0
         for p in self.params:
             if p.dtype != torch.float32:
@@ -73,7 +78,26 @@ class FlatTrainer:
             self.slots.append(slot)
             if use_grad_slots:
                 p._snn_grad_slot = slot
+            if p.dim() == 4 and self.flat_wt is not None:
+                o, i, kh, kw = p.shape
+                table.append([off, o, kh * kw, i])
+                p._snn_wt = self.flat_wt[off:off + p.numel()].view(i, kh, kw, o)
+                p._snn_wt_version = -1  # not valid yet
+                self._conv_params.append(p)
             off += p.numel()
+        self._wt_table = torch.tensor(table, dtype=torch.int64, device=dev) if table else None
+        self.refresh_transposed_weights()
+
+    def refresh_transposed_weights(self) -> None:
+        """Re-derive every ``p._snn_wt`` from the current weights (one launch).  ``_Conv2d.backward`` uses a cached
+        transpose only while the parameter's version counter still matches, so a ``load_state_dict`` or any other
+        torch-side in-place update simply falls back to the per-layer transpose until the next call."""
+        if self._wt_table is None:
+            return
+        _hip.call("snn_weight_transpose_batched", self.flat_param.data_ptr(), self.flat_wt.data_ptr(),
+                  self._wt_table.data_ptr(), len(self._conv_params), torch.cuda.current_stream().cuda_stream)
+        for p in self._conv_params:
+            p._snn_wt_version = p._version
 
     # ------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -111,6 +135,7 @@ class FlatTrainer:
                       self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.flat_param.numel(), self.lr,
                       self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / self.world,
                       torch.cuda.current_stream().cuda_stream)
+            self.refresh_transposed_weights()
         else:
             raise RuntimeError("FlatTrainer.step: parameters are not on a HIP device; the optimiser kernel has no "
                                "CPU fallback")
@@ -152,3 +177,5 @@ def broadcast_parameters(trainer: FlatTrainer, src: int = 0) -> None:
     """Make every rank start from rank ``src``'s weights (DDP does this at construction)."""
     if trainer.world > 1:
         dist.broadcast(trainer.flat_param, src=src, group=trainer.group)
+        if trainer.flat_param.is_cuda:
+            trainer.refresh_transposed_weights()  # the weights changed behind torch's version counters
