@@ -118,3 +118,43 @@ def test_odd_channel_counts_and_tiny_batches(S):
         for pd, pr in zip(blk.parameters(), ref.parameters()):
             if pr.grad.norm() > 1e-7:
                 assert rel_err(pd.grad, pr.grad) < 1e-3
+
+
+def test_early_targets_and_cached_transposes_match_the_plain_path(S):
+    """Step 2+ computes the anchor targets on the side stream before the forward pass and uses FlatTrainer's cached
+    w^T: same loss and same gradients (bitwise) as the first-step path; new labels / a torch-side weight update are
+    picked up."""
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 3, 2, 32, 48
+    X = synthetic_events(T, B, H, W, p=0.1).cuda()
+    labels, labels2 = synthetic_labels(B).cuda(), synthetic_labels(B, seed=7).cuda()
+    torch.manual_seed(2)
+    m = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    tr = FlatTrainer(m, lr=1e-3)
+
+    def grads(lab):
+        tr.zero_grad()
+        loss = m.training_step((X, lab))
+        loss.backward()
+        tr.synchronize()
+        return loss.detach().clone(), tr.flat_grad.clone()
+
+    m._anchor_cache = {}
+    l_plain, g_plain = grads(labels)          # no cached anchors: targets after the forward pass
+    assert m._anchor_cache
+    l_early, g_early = grads(labels)          # targets computed early on the side stream
+    assert torch.equal(l_plain, l_early) and torch.equal(g_plain, g_early)
+    l_new, _ = grads(labels2)                 # the early path follows the labels of the step
+    m._anchor_cache = {}
+    l_new_plain, _ = grads(labels2)
+    assert torch.equal(l_new, l_new_plain) and not torch.equal(l_new, l_plain)
+    # a torch-side in-place weight update invalidates the cached transposes (per-layer fallback)
+    conv_w = next(p for p in m.parameters() if p.dim() == 4 and p.shape[1] > 2)
+    with torch.no_grad():
+        conv_w.mul_(1.5)
+    assert conv_w._snn_wt_version != conv_w._version
+    _, g_fallback = grads(labels)
+    tr.refresh_transposed_weights()
+    assert conv_w._snn_wt_version == conv_w._version
+    _, g_cached = grads(labels)
+    assert torch.equal(g_fallback, g_cached)
