@@ -299,6 +299,27 @@ class GradSlot:
         return acc
 
 
+_NBT_BATCH = None  # while a model-level forward runs: deferred ``num_batches_tracked`` increments (see soda.py)
+
+
+def begin_counter_batch() -> None:
+    global _NBT_BATCH
+    _NBT_BATCH = []
+
+
+def flush_counter_batch() -> None:
+    """Apply the deferred BatchNorm ``num_batches_tracked`` increments in one multi-tensor launch (22 BatchNorms
+    = 22 one-element kernels per step otherwise)."""
+    global _NBT_BATCH
+    pending, _NBT_BATCH = _NBT_BATCH, None
+    if pending:
+        by_inc = {}
+        for t, inc in pending:
+            by_inc.setdefault(inc, []).append(t)
+        for inc, tensors in by_inc.items():
+            torch._foreach_add_(tensors, inc)
+
+
 FUSE_OUTER_ADDEND = not os.environ.get("SNN_NO_OUTER_ADDEND")  # bisecting aid
 
 
@@ -674,7 +695,10 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
         momentum = bn.momentum
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(seq.shape[0])
+            if _NBT_BATCH is not None:
+                _NBT_BATCH.append((bn.num_batches_tracked, int(seq.shape[0])))  # one fused update per forward
+            else:
+                bn.num_batches_tracked.add_(seq.shape[0])
     v0 = i0 = None
     if state is not None:
         if neuron == _hip.NEURON_SYNAPSE:

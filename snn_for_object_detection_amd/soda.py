@@ -85,10 +85,15 @@ class SODa(nn.Module):
         return preds
 
     def _forward_impl(self, X: torch.Tensor, state: Optional[ListState]):
+        from . import functional as HF
         state = [None] * 3 if state is None else state
-        base_out, state[0] = self.base_net.forward(X, state[0])
-        neck_out, state[1] = self.neck_net.forward(base_out, state[1])
-        anchors, cls_preds, bbox_preds, state[2] = self.head_net.forward(neck_out, state[2])
+        HF.begin_counter_batch()
+        try:
+            base_out, state[0] = self.base_net.forward(X, state[0])
+            neck_out, state[1] = self.neck_net.forward(base_out, state[1])
+            anchors, cls_preds, bbox_preds, state[2] = self.head_net.forward(neck_out, state[2])
+        finally:
+            HF.flush_counter_batch()
         return (anchors, cls_preds, bbox_preds), state
 
     # ------------------------------------------------------------------ steps
