@@ -418,9 +418,20 @@ class _Conv2d(Function):
                     if tuple(other2.shape) == tuple(dx.shape):
                         addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
                         outer_fused = (o_acc, o_key, key2)
+            chained = False
+            if (acc is not None and acc[0].result is not None and addend is None and acc[1] not in acc[0].fused
+                    and tuple(acc[0].result.shape) == tuple(dx.shape)):
+                # a sibling convolution already produced (its gradient + the fused deposits) for this tensor: add
+                # that here and become the accumulated result (two convolutions on one input: the C2f split)
+                prev = acc[0].result
+                addend, ld_add = prev.data_ptr(), cl_stride(prev)
+                chained = True
             _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
                       Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, st)
-            if acc is not None and acc[0].result is None:
+            if acc is not None and (acc[0].result is None or chained):
+                if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
+                    acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
+                    acc[0].outer[0].fused[acc[0].outer[1]] = dx    # fanout will hand back: the new total
                 acc[0].result = dx
                 acc[0].fused[acc[1]] = dx
             if outer_fused is not None:
