@@ -43,6 +43,8 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
         return PEAK_BF16_MATRIX_TFLOPS / 3.0, "bf16 dense MFMA / 3 products"
     if prec == "bf16x6":
         return PEAK_BF16_MATRIX_TFLOPS / 6.0, "bf16 dense MFMA / 6 products"
+    if prec == "fp16x3":
+        return PEAK_BF16_MATRIX_TFLOPS / 3.0, "fp16 dense MFMA / 3 products"
     return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA"
 
 
@@ -103,8 +105,9 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
-    ap.add_argument("--forward-precision", choices=("bf16x6", "fp32"), default="bf16x6",
-                    help="forward conv arithmetic: bf16x6 = 3-way bf16 split, 6 products, fp32-grade accuracy")
+    ap.add_argument("--forward-precision", choices=("fp16x3", "bf16x6", "fp32"), default="fp16x3",
+                    help="forward conv arithmetic: fp16x3 = 2 fp16 pieces, 3 products (fp32-grade for |x| < 4094); "
+                         "bf16x6 = 3 bf16 pieces, 6 products (fp32-grade, any range); fp32 = exact fp32 MFMA")
     ap.add_argument("--backward-precision", choices=("bf16x3", "fp32"), default="bf16x3",
                     help="arithmetic of the backward convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,9 +250,11 @@ def main():
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
                 "sync_batchnorm": bool(args.sync_bn and world > 1),
                 "arithmetic": "fp32 storage and accumulation; forward conv "
-                              + ("bf16x6 split products (3-way bf16 split of both operands, fp32-grade: rel 5e-7 vs "
-                                 "fp64, same as the fp32 MFMA)" if args.forward_precision == "bf16x6"
-                                 else "exact fp32 MFMA")
+                              + {"fp16x3": "fp16x3 split products (two fp16 pieces per operand after exact 2^k "
+                                           "pre-scaling, hh+hl+lh; fp32-grade: rel 5e-7 vs fp64, same as the fp32 MFMA)",
+                                 "bf16x6": "bf16x6 split products (3-way bf16 split of both operands, fp32-grade: "
+                                           "rel 5e-7 vs fp64, same as the fp32 MFMA)",
+                                 "fp32": "exact fp32 MFMA"}[args.forward_precision]
                               + "; backward conv "
                               + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, rel 1e-5)"
                                  if args.backward_precision == "bf16x3" else "exact fp32 MFMA"),

@@ -100,9 +100,15 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
  * relative error ~2^-16 per product. */
 int snn_set_backward_precision(int mode);
 int snn_get_backward_precision(void);
-/* Arithmetic of the FORWARD convolution: 3 (default) = "bf16 x 6": three-way bf16 split of both operands
- * (h + m + l = all 24 significant bits) and the six leading products with fp32 accumulation - fp32-grade accuracy
- * (dropped terms 2^-25; measured relative error vs fp64 equal to the fp32 MFMA's); 0 = exact fp32 MFMA (fmaf chain). */
+/* Arithmetic of the FORWARD convolution (storage and accumulation are fp32 in every mode):
+ *   4 (default) = "fp16 x 3": both operands split into two fp16 pieces (11 + 11 significant bits) after exact
+ *       power-of-two pre-scaling (weights x 2^8, activations x 2^4), products hh + hl + lh with fp32 accumulation:
+ *       relative error 2^-22 (measured 5e-7 vs fp64, equal to the fp32 MFMA's) at half the matrix work of mode 3.
+ *       Range contract: |x| < 4094 and |w| < 255 (beyond: inf/NaN in the output - visible, not silent); values
+ *       below |x| = 0.008 / |w| = 5e-4 keep an ABSOLUTE accuracy of 4e-9 / 2e-10 instead of 22 bits.
+ *   3 = "bf16 x 6": three-way bf16 split of both operands (h + m + l = all 24 significant bits) and the six leading
+ *       products - fp32-grade for any fp32 range.
+ *   0 = exact fp32 MFMA (fmaf chain). */
 int snn_set_forward_precision(int mode);
 int snn_get_forward_precision(void);
 

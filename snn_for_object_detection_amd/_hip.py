@@ -93,7 +93,7 @@ def load():
     # optional process-wide arithmetic overrides (defaults: forward bf16x6, backward bf16x3)
     fwd = os.environ.get("SNN_FORWARD_PRECISION")
     if fwd:
-        lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3}[fwd])
+        lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3, "fp16x3": 4}[fwd])
     bwd = os.environ.get("SNN_BACKWARD_PRECISION")
     if bwd:
         lib.snn_set_backward_precision({"fp32": 0, "bf16x3": 1}[bwd])

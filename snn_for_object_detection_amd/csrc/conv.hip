@@ -74,6 +74,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// fp16 x 3 ("SPLIT = 4"): operands are pre-scaled by powers of two (exact) so that the LOW pieces stay in fp16's normal
+// range: weights x 2^8 (|w| < 255), activations x 2^4 (|x| < 4094; full 22-bit precision down to |x| = 0.008, graceful
+// below: absolute error 4e-9).  The accumulators are scaled back by 2^-12 in the epilogue.
+constexpr float kF16WeightScale = 256.0f;
+constexpr float kF16ActScale = 16.0f;
+constexpr float kF16Unscale = 1.0f / (kF16WeightScale * kF16ActScale);
 constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS images: 80 B keeps ds_read_b128 conflict-free
 
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
@@ -84,6 +93,10 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 //   lo = bf16(x - hi); the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
 //   (relative error ~2^-16 per product instead of 2^-24, at 16/3 of the fp32 matrix rate).  Default for the
 //   data gradient, where a 1e-5 relative error is far inside the gradient tolerance.
+// SPLIT = 4: "fp16 x 3": x = h + l with fp16 pieces (11 + 11 significant bits), products hh + hl + lh on
+//   v_mfma_f32_32x32x16_f16: relative error 2^-22, fp32-grade like bf16 x 6 at HALF its matrix work and two LDS
+//   images instead of three.  fp16 has the range for forward values (|x| < 65504; activations of a normalised
+//   spiking net are O(1), weights are pre-scaled by 2^8), not for gradients - the backward kernels stay on bf16.
 // SPLIT = 3: "bf16 x 6": three-way split x = h + m + l (24 significant bits, i.e. the fp32 value itself) and the
 //   six products hh + hm + mh + mm + hl + lh; the dropped terms are 2^-25 relative - fp32-grade accuracy at
 //   16/6 of the fp32 matrix rate.
@@ -101,8 +114,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int A_BYTES = SPLIT ? SPLIT * BM * LDB * 2 : BM * LDK * 4;
-    constexpr int B_BYTES = SPLIT ? SPLIT * BN * LDB * 2 : BN * LDK * 4;
+    constexpr int NPIECE = SPLIT == 3 ? 3 : 2;  // 16-bit images per operand
+    constexpr int A_BYTES = SPLIT ? NPIECE * BM * LDB * 2 : BM * LDK * 4;
+    constexpr int B_BYTES = SPLIT ? NPIECE * BN * LDB * 2 : BN * LDK * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = reinterpret_cast<float*>(smem + A_BYTES);
@@ -364,10 +378,24 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         // shadow - about 4 VALU per MFMA gap, which the matrix pipe hides - and then issues the loads of tile
         // k+2.  Between the two barriers only the LDS writes remain.  Measured without this (convert + write
         // between the barriers): MFMA pipe busy 36 % even with the global loads removed.
-        constexpr int NP = SPLIT;                       // bf16 images per operand
+        constexpr int NP = NPIECE;                      // 16-bit images per operand
         constexpr int NPROD = SPLIT == 3 ? 6 : 3;       // MFMA products per accumulator and k16
         bf16x4 pa[4][NP], pb[BROWS][NP];                // [.][0] hi, [.][1] lo, [.][2] mid
-        auto convert = [&](const f32x4& v, bf16x4* out) {
+        auto convert = [&](const f32x4& v, bf16x4* out, float scale) {
+            if constexpr (SPLIT == 4) {  // fp16 pieces (v_cvt_pk_f16_f32); the residual x - hi is exact in fp32
+                u32x2 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float a = v[e] * scale, b = v[e + 1] * scale;
+                    const f16x2 ph = __builtin_convertvector(f32x2{a, b}, f16x2);  // RNE: out of range -> inf (loud)
+                    const f16x2 pl = __builtin_convertvector(f32x2{a - (float)ph[0], b - (float)ph[1]}, f16x2);
+                    hi[e >> 1] = __builtin_bit_cast(unsigned, ph);
+                    lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+                }
+                out[0] = __builtin_bit_cast(bf16x4, hi);
+                out[1] = __builtin_bit_cast(bf16x4, lo);
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
                 f32x2 rest = {v[e], v[e + 1]};
@@ -423,6 +451,14 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {  // small terms first
+                    if constexpr (SPLIT == 4) {
+                        const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]), xal = __builtin_bit_cast(f16x8, al[i]);
+                        const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, acc[i][j], 0, 0, 0);
+                        continue;
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     if (SPLIT == 3) {
@@ -440,9 +476,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         if (g.Ktot > 0) {
             load_tiles_fast(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j]);
+            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j], kF16ActScale);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j]);
+            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
             write_tiles();
             load_tiles_fast(BK);
         }
@@ -456,7 +492,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
             mfma_group(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j]);
+            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j], kF16ActScale);
             // shape the schedule: operand reads, then every MFMA followed by its share of the conversion VALU
             __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
@@ -468,7 +504,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             STAMP(0);
             mfma_group(1);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j]);
+            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
             __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -580,7 +616,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] =
+                    SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e];  // undo the operand pre-scales
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 32 / RPP; ++pass) {
@@ -1340,8 +1378,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // backward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 x 3 split products (snn_set_backward_precision)
 static int g_backward_split = 1;
-// forward arithmetic: 3 = bf16 x 6 (default; fp32-grade, measured 5e-7 vs fp64 like the fp32 MFMA), 0 = exact fp32 MFMA
-static int g_forward_split = 3;
+// forward arithmetic: 4 = fp16 x 3 (default; fp32-grade for |x| < 4094, |w| < 255), 3 = bf16 x 6 (fp32-grade, any
+// range), 0 = exact fp32 MFMA
+static int g_forward_split = 4;
 
 template <bool DGRAD, int SPLIT>
 static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
@@ -1367,7 +1406,7 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else if (vec)                                                                                       \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, false>), grid, dim3(kThreads), 0, \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, (SPLIT == 4 ? 3 : SPLIT), false>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else                                                                                                \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0, false>), grid, dim3(kThreads), 0, st, \
@@ -1409,9 +1448,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
                                                               float* __restrict__ out, DirectGeom g,
                                                               const float* __restrict__ addend, int64_t ld_add,
                                                               const float* __restrict__ addend2, int64_t ld_add2) {
-    static_assert(WM * WN == 4 && (SPLIT == 2 || SPLIT == 3) && (TPS == 1 || TPS == 3), "configuration");
+    static_assert(WM * WN == 4 && (SPLIT == 2 || SPLIT == 3 || SPLIT == 4) && (TPS == 1 || TPS == 3), "configuration");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NP = SPLIT, NPROD = SPLIT == 3 ? 6 : 3;
+    constexpr int NP = SPLIT == 3 ? 3 : 2, NPROD = SPLIT == 3 ? 6 : 3;
     constexpr int SPC = 9 / TPS;                 // stages per 32-channel chunk
     constexpr int BJ = TPS * BN / 32;            // weight f32x4 per thread and stage
     constexpr int AJ = (DHROWS * 8 + kThreads - 1) / kThreads;  // halo f32x4 per thread and chunk (6)
@@ -1508,7 +1547,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
             rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff, 0, 0));
         }
     };
-    auto convert = [&](const f32x4& v, bf16x4* o) {  // o[0] hi, o[1] lo, o[2] mid
+    auto convert = [&](const f32x4& v, bf16x4* o, float scale) {  // o[0] hi, o[1] lo, o[2] mid
+        if constexpr (SPLIT == 4) {  // fp16 pieces (see k_conv_gather)
+            u32x2 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const float a = v[e] * scale, b = v[e + 1] * scale;
+                const f16x2 ph = __builtin_convertvector(f32x2{a, b}, f16x2);  // RNE: out of range -> inf (loud)
+                const f16x2 pl = __builtin_convertvector(f32x2{a - (float)ph[0], b - (float)ph[1]}, f16x2);
+                hi[e >> 1] = __builtin_bit_cast(unsigned, ph);
+                lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+            }
+            o[0] = __builtin_bit_cast(bf16x4, hi);
+            o[1] = __builtin_bit_cast(bf16x4, lo);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
             f32x2 rest = {v[e], v[e + 1]};
@@ -1533,7 +1586,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
         for (int j = 0; j < AJ; ++j) {
             if (a_row[j] < 0) continue;
             bf16x4 o[3];
-            convert(ra[j], o);
+            convert(ra[j], o, kF16ActScale);
 #pragma unroll
             for (int pz = 0; pz < NP; ++pz) *reinterpret_cast<bf16x4*>(&Ai[pz][a_row[j] * LDB + kq]) = o[pz];
         }
@@ -1576,6 +1629,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {  // small terms first; pieces: 0 hi, 1 lo, 2 mid
+                if constexpr (SPLIT == 4) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, f.a[i][0]), al = __builtin_bit_cast(f16x8, f.a[i][1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, f.b[j][0]), bl = __builtin_bit_cast(f16x8, f.b[j][1]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                    continue;
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], acc[i][j], 0, 0, 0);
                 if (SPLIT == 3) {
@@ -1607,7 +1668,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         write_a();
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j]);
+        for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j], kF16WeightScale);
         write_b();
         load_a(1);
         load_b(1);
@@ -1632,7 +1693,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
                 mfma_frag(fr[gq & 1]);
                 if (gq == 0) {
 #pragma unroll
-                    for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j]);  // weights of stage s+1, in the MFMA shadow
+                    for (int j = 0; j < BJ; ++j) convert(rb[j], pb[j], kF16WeightScale);  // stage s+1, in the MFMA shadow
                 }
             }
             // schedule shape: [reads of group g+1] then the MFMAs of group g, each followed by its share of the VALU
@@ -1678,7 +1739,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
     #pragma unroll
             for (int j = 0; j < TN; ++j)
     #pragma unroll
-                for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e)
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] =
+                        SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e];
             __syncthreads();
     #pragma unroll
             for (int pass = 0; pass < 32 / RPP; ++pass) {
@@ -1721,7 +1784,7 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
     // measured: a win (12-15 %) for <= 32 output channels; at 64 the implicit-GEMM kernel is as fast or faster
     // (both are bound by LDS operand traffic there), so it stays the default; SNN_CONV_DIRECT_MAX_OC=64 to compare
     static const int max_oc = getenv("SNN_CONV_DIRECT_MAX_OC") ? atoi(getenv("SNN_CONV_DIRECT_MAX_OC")) : 32;
-    if (off || (split != 2 && split != 3) || IC % BK != 0 || OC > max_oc || OC > 64 || OC % 4 != 0) return -1;
+    if (off || (split != 2 && split != 3 && split != 4) || IC % BK != 0 || OC > max_oc || OC > 64 || OC % 4 != 0) return -1;
     if (ldi % 4 != 0 || !aligned16(in) || !aligned16(wk)) return -1;
     if ((int64_t)H * W * ldi * 4 >= 0x7fffffffLL || (int64_t)OC * 9 * IC * 4 >= 0x7fffffffLL) return -1;
     DirectGeom g;
@@ -1738,7 +1801,7 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
     g.out_vec = (ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
     // persistent: at most (CUs per XCD) x (resident blocks per CU) blocks per XCD
-    const int resident = (OC <= 32 && split == 2) ? 3 : 2;
+    const int resident = (OC <= 32 && split != 3) ? 3 : 2;
     int nbx = (SNN_NUM_CU / 8) * resident;
     if (nbx > g.tiles_per_xcd) nbx = g.tiles_per_xcd;
     dim3 grid((unsigned)(nbx * 8));
@@ -1747,9 +1810,11 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
                        g, addend, ld_add, addend2, ld_add2)
     if (OC <= 32) {
         if (split == 3) SNN_DIRECT_LAUNCH(32, 4, 1, 3, 3);
+        else if (split == 4) SNN_DIRECT_LAUNCH(32, 4, 1, 4, 3);
         else SNN_DIRECT_LAUNCH(32, 4, 1, 2, 3);
     } else {
         if (split == 3) SNN_DIRECT_LAUNCH(64, 2, 2, 3, 1);
+        else if (split == 4) SNN_DIRECT_LAUNCH(64, 2, 2, 4, 3);
         else SNN_DIRECT_LAUNCH(64, 2, 2, 2, 3);
     }
 #undef SNN_DIRECT_LAUNCH
@@ -1780,7 +1845,8 @@ extern "C" int snn_set_backward_precision(int mode) {
 }
 extern "C" int snn_get_backward_precision(void) { return g_backward_split; }
 extern "C" int snn_set_forward_precision(int mode) {
-    SNN_REQUIRE(mode == 0 || mode == 3, "snn_set_forward_precision: mode must be 0 (fp32) or 3 (bf16x6)");
+    SNN_REQUIRE(mode == 0 || mode == 3 || mode == 4,
+                "snn_set_forward_precision: mode must be 0 (fp32), 3 (bf16x6) or 4 (fp16x3)");
     g_forward_split = mode;
     return 0;
 }
@@ -1810,6 +1876,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
                                              nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
         if (rc >= 0) return rc;
     }
+    if (g_forward_split == 4)
+        return launch_gather<false, 4>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (g_forward_split == 3)
         return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");

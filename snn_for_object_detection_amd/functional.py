@@ -49,18 +49,23 @@ def get_backward_precision() -> str:
     return ("fp32", "bf16x3")[_hip.query("snn_get_backward_precision")]
 
 
+DEFAULT_FORWARD_PRECISION = "fp16x3"
+DEFAULT_BACKWARD_PRECISION = "bf16x3"
+
+
 def set_forward_precision(mode: str) -> None:
-    """Forward convolution arithmetic: ``"bf16x6"`` (default: three-way bf16 split of both operands = all 24
-    significant bits, six products, fp32 accumulation; fp32-grade accuracy at 16/6 of the fp32 MFMA rate) or
-    ``"fp32"`` (exact fp32 MFMA, an fmaf chain)."""
-    modes = {"fp32": 0, "bf16x6": 3}
+    """Forward convolution arithmetic (fp32 storage and accumulation in every mode): ``"fp16x3"`` (default: two
+    fp16 pieces per operand after exact power-of-two pre-scaling, three products; fp32-grade for conv inputs
+    |x| < 4094 and weights |w| < 255 - spikes and normalised activations), ``"bf16x6"`` (three bf16 pieces, six
+    products: fp32-grade for any range, half the speed) or ``"fp32"`` (exact fp32 MFMA, an fmaf chain)."""
+    modes = {"fp32": 0, "bf16x6": 3, "fp16x3": 4}
     if mode not in modes:
         raise ValueError(f"forward precision must be one of {sorted(modes)}")
     _hip.call("snn_set_forward_precision", modes[mode])
 
 
 def get_forward_precision() -> str:
-    return {0: "fp32", 3: "bf16x6"}[_hip.query("snn_get_forward_precision")]
+    return {0: "fp32", 3: "bf16x6", 4: "fp16x3"}[_hip.query("snn_get_forward_precision")]
 
 
 # ------------------------------------------------------------------------------------------- helpers

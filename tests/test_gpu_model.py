@@ -21,7 +21,8 @@ def S(hip_lib):
     return pkg
 
 
-@pytest.mark.parametrize("fwd,bwd", [("bf16x6", "bf16x3"), ("fp32", "fp32")], ids=["default-arith", "exact-fp32"])
+@pytest.mark.parametrize("fwd,bwd", [("fp16x3", "bf16x3"), ("bf16x6", "bf16x3"), ("fp32", "fp32")],
+                         ids=["default-arith", "bf16x6-forward", "exact-fp32"])
 def test_tiny_yolo_train_step_matches_oracle(S, fwd, bwd):
     T, B, H, W = 4, 2, 32, 48
     S.functional.set_forward_precision(fwd)
@@ -29,8 +30,8 @@ def test_tiny_yolo_train_step_matches_oracle(S, fwd, bwd):
     try:
         _train_step_vs_oracle(S, T, B, H, W)
     finally:
-        S.functional.set_forward_precision("bf16x6")
-        S.functional.set_backward_precision("bf16x3")
+        S.functional.set_forward_precision(S.functional.DEFAULT_FORWARD_PRECISION)
+        S.functional.set_backward_precision(S.functional.DEFAULT_BACKWARD_PRECISION)
 
 
 def _train_step_vs_oracle(S, T, B, H, W):

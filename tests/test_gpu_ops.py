@@ -392,7 +392,7 @@ def test_backward_precision_modes_against_fp64(HF, mode, tol):
         HF.set_backward_precision("fp8")
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32", "fp16x3"])
 def test_forward_precision_modes_against_fp64(HF, mode):
     """Both forward arithmetics are fp32-grade: the 3-way bf16 split (6 products) carries all 24 significant bits."""
     torch.manual_seed(13)
@@ -410,3 +410,26 @@ def test_forward_precision_modes_against_fp64(HF, mode):
         HF.set_forward_precision(prev)
     with pytest.raises(ValueError):
         HF.set_forward_precision("bf16")
+
+
+def test_fp16x3_range_contract(HF):
+    """Default forward arithmetic: fp32-grade inside its range, graceful below it, loud (non-finite) above it."""
+    torch.manual_seed(14)
+    prev = HF.get_forward_precision()
+    try:
+        HF.set_forward_precision("fp16x3")
+        w = torch.randn(64, 64, 3, 3) / 24.0
+        for scale, tol in [(1.0, 1.5e-6), (200.0, 1.5e-6), (1e-2, 1.5e-6), (1e-4, 1e-4)]:
+            x = torch.randn(2, 2, 64, 12, 16) * scale
+            ref = F.conv2d(x.double().flatten(0, 1), w.double(), padding=1)
+            y = HF.conv2d(x.cuda(), w.cuda(), stride=1, padding=1)
+            assert rel_err(y.flatten(0, 1), ref) < tol, scale
+        x = torch.randn(1, 1, 64, 12, 16)
+        x[0, 0, 3, 5, 5] = 1e5   # beyond the fp16 range after the 2^4 pre-scale
+        y = HF.conv2d(x.cuda(), w.cuda(), stride=1, padding=1)
+        assert not torch.isfinite(y).all()
+        HF.set_forward_precision("bf16x6")   # the any-range mode handles the same input
+        y = HF.conv2d(x.cuda(), w.cuda(), stride=1, padding=1)
+        assert torch.isfinite(y).all()
+    finally:
+        HF.set_forward_precision(prev)
