@@ -221,12 +221,20 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         for (int j = 0; j < 4; ++j) {
             const int relpix = (a_base[j] - (int)(img0 * ipix)) + a_y0[j] * g.IW + a_x0[j];
             a_rel[j] = (relpix * (int)g.ldi + kq) * 4;
-            unsigned mask = 0;
-            for (int th = 0, t = 0; th < (DGRAD ? g.nkh : g.KH); ++th)
-                for (int tw = 0; tw < tw_n; ++tw, ++t) {
-                    const int iy = DGRAD ? a_y0[j] - th : a_y0[j] + th, ix = DGRAD ? a_x0[j] - tw : a_x0[j] + tw;
-                    if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) mask |= 1u << t;
-                }
+            // bit (th * ntw + tw) = tap inside the image: row validity x column validity, branch-free (the taps of a
+            // FAST launch are at most 5 x 5: ntaps <= 31)
+            const int nth = DGRAD ? g.nkh : g.KH;
+            unsigned xm = 0, mask = 0;
+#pragma unroll
+            for (int tw = 0; tw < 6; ++tw) {
+                const int ix = DGRAD ? a_x0[j] - tw : a_x0[j] + tw;
+                xm |= (tw < tw_n && (unsigned)ix < (unsigned)g.IW) ? 1u << tw : 0u;
+            }
+#pragma unroll
+            for (int th = 0; th < 6; ++th) {
+                const int iy = DGRAD ? a_y0[j] - th : a_y0[j] + th;
+                mask |= (th < nth && (unsigned)iy < (unsigned)g.IH) ? xm << (th * tw_n) : 0u;
+            }
             a_mask[j] = a_ok[j] ? mask : 0u;
         }
 #pragma unroll
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     }
     const unsigned fast_tw_n = DGRAD ? g.nkw : g.KW;
     const unsigned fast_tw_one = fast_tw_n == 1 ? 1u : 0u;  // magic_u32(1) is 0: q = umulhi(n, 0) + n
-    auto load_tiles_fast = [&](int k0n) {  // k0n is block-uniform: everything up to the per-row adds is scalar
+    auto load_tiles_fast = [&](int k0n, f32x4 (&ra)[4], f32x4 (&rb)[BROWS]) {  // k0n is block-uniform: everything up to the per-row adds is scalar
         const bool kin = k0n < g.Ktot;
         const int tap = (int)__umulhi((unsigned)k0n, g.magic_ic);  // IC >= 32 here
         const int c0 = k0n - tap * g.IC;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
 
     auto load_tiles = [&](int k0) {
         if (FAST) {
-            load_tiles_fast(k0);
+            load_tiles_fast(k0, ra, rb);
             return;
         }
         const int kk = k0 + kq;
@@ -474,13 +482,16 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         constexpr int CONV_OPS = SPLIT == 3 ? 24 : 14;   // VALU per converted f32x4 (approx.)
         constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM, VPG_B = (BROWS * CONV_OPS + NM - 1) / NM;
         if (g.Ktot > 0) {
-            load_tiles_fast(0);
+            // both first tiles are requested back to back (the accumulators are not live yet, registers are free):
+            // one exposed memory latency per block instead of two
+            f32x4 ra0[4], rb0[BROWS];
+            load_tiles_fast(0, ra0, rb0);
+            load_tiles_fast(BK, ra, rb);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j], kF16ActScale);
+            for (int j = 0; j < 4; ++j) convert(ra0[j], pa[j], kF16ActScale);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
+            for (int j = 0; j < BROWS; ++j) convert(rb0[j], pb[j], kF16WeightScale);
             write_tiles();
-            load_tiles_fast(BK);
         }
         __syncthreads();
 #ifdef SNN_STAMP
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
-            load_tiles_fast(k0 + 2 * BK);
+            load_tiles_fast(k0 + 2 * BK, ra, rb);
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -620,34 +631,51 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
                 stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] =
                     SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e];  // undo the operand pre-scales
         __syncthreads();
+        // Address arithmetic: for the common case (output pixel = GEMM row) everything but a per-lane 32-bit offset
+        // is wave-uniform: base pointers of the 32-row group live in SGPRs, the lane adds (its row) * ld + channel.
+        // (The general form spent ~50 64-bit multiplies per wave here - a third of the epilogue.)
+        const bool linear = !(DGRAD && g.stride > 1);
+        const int64_t mrow0 = m0 + (wm * TM + i) * 32;   // wave-uniform
+        const int lrow = lane_id / LPR;
+        const int c4 = (lane_id % LPR) * 4;
+        const int n = n0 + wn * TN * 32 + c4;
+        float* out_g = out + mrow0 * g.ldo;
+        const float* ad1_g = addend ? addend + mrow0 * ld_add : nullptr;
+        const float* ad2_g = addend2 ? addend2 + mrow0 * ld_add2 : nullptr;
+        const int o_l = lrow * (int)g.ldo + n, a1_l = lrow * (int)ld_add + n, a2_l = lrow * (int)ld_add2 + n;
 #pragma unroll
         for (int pass = 0; pass < 32 / RPP; ++pass) {
-            const int row = pass * RPP + lane_id / LPR;
-            const int c4 = (lane_id % LPR) * 4;
-            const int64_t m = m0 + (wm * TM + i) * 32 + row;
-            const int n = n0 + wn * TN * 32 + c4;
+            const int row = pass * RPP + lrow;
+            const int64_t m = mrow0 + row;
             if (m >= g.Mtot || n >= g.OC) continue;
-            int64_t pix = m;
-            if (DGRAD && g.stride > 1) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
+            float* dst;
+            const float *a1p, *a2p;
+            if (linear) {
+                dst = out_g + (o_l + pass * RPP * (int)g.ldo);
+                a1p = ad1_g + (a1_l + pass * RPP * (int)ld_add);
+                a2p = ad2_g + (a2_l + pass * RPP * (int)ld_add2);
+            } else {
                 const unsigned t = (unsigned)m / (unsigned)g.OWc;
                 const int b = (int)((unsigned)m - t * (unsigned)g.OWc);
                 const unsigned img = t / (unsigned)g.OHc;
                 const int a = (int)(t - img * (unsigned)g.OHc);
-                pix = ((int64_t)img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
+                const int64_t pix = ((int64_t)img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
+                dst = out + pix * g.ldo + n;
+                a1p = addend + pix * ld_add + n;
+                a2p = addend2 + pix * ld_add2 + n;
             }
-            f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
-            float* dst = out + pix * g.ldo + n;
             if (ovec && n + 3 < g.OC) {
-                if (addend) v += *reinterpret_cast<const f32x4*>(addend + pix * ld_add + n);  // fused accumulation
-                if (addend2) v += *reinterpret_cast<const f32x4*>(addend2 + pix * ld_add2 + n);
+                if (addend) v += *reinterpret_cast<const f32x4*>(a1p);  // fused accumulation
+                if (addend2) v += *reinterpret_cast<const f32x4*>(a2p);
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (n + q < g.OC) {
                         float o = v[q];
-                        if (addend) o += addend[pix * ld_add + n + q];
-                        if (addend2) o += addend2[pix * ld_add2 + n + q];
+                        if (addend) o += a1p[q];
+                        if (addend2) o += a2p[q];
                         dst[q] = o;
                     }
             }
@@ -1391,6 +1419,7 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
     static const bool no_fast = getenv("SNN_CONV_NO_FAST") != nullptr;  // tuning / bisecting aid
     const bool fast = vec && !no_fast && g.IC % BK == 0 && ntaps >= 1 && ntaps <= 31 &&
+                      (DGRAD ? g.nkh : g.KH) <= 6 && (DGRAD ? g.nkw : g.KW) <= 6 &&
                       (int64_t)g.IH * g.IW * g.ldi * 16 < 0x7fffffffLL && (int64_t)g.OC * g.KtotFull * 4 < 0x7fffffffLL;
     ConvGeom gg = g;
     gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&

@@ -29,6 +29,7 @@ for _ in range(3):
         _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, st)
 torch.cuda.synchronize()
 nblk = min(2048, (N * (H if op == "dgrad" else Ho) * (W if op == "dgrad" else Wo) + 127) // 128)
+nblk = nblk // 8 * 8  # XCD-aware order: the last ids may be padding blocks
 buf = np.zeros(2048 * 8, dtype=np.uint64)
 lib.snn_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = lib.snn_debug_stamps(buf.ctypes.data, 2048 * 8)
