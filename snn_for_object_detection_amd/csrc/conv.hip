@@ -1108,20 +1108,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* _
 //     address arithmetic; dy rows past the split's last pixel fall off the end of the buffer resource;
 //   * tile k+1 is converted to its bf16 pieces in the shadow of tile k's MFMAs and the loads of tile k+2 are
 //     issued before the barrier; between the two barriers only the LDS writes remain.
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int WBK>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, WgradGeom g) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
     constexpr int DG = BMc / 4, XG = BNk / 4;
-    constexpr int GPP = kThreads / 8;
+    // WBK pixels per LDS stage: 32 for the large tiles; 64 for the small ones, whose 6-MFMA stages were shorter than
+    // the memory latency they have to cover (PMC: 58 % of the wave cycles parked in s_waitcnt / barriers)
+    static_assert(WBK == 32 || WBK == 64, "stage length");
+    constexpr int LDW = WBK + 8;      // bf16 row pitch: 80 / 144 bytes, conflict-free ds_read_b128 fragments
+    constexpr int NQ = WBK / 4;       // pixel quads per stage
+    constexpr int GPP = kThreads / NQ;
     constexpr int DQ = (DG + GPP - 1) / GPP, XQ = (XG + GPP - 1) / GPP;
-    __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDB];
-    __shared__ __attribute__((aligned(16))) int Pinfo[2][WB_K][4];  // {byte offset of the pixel origin, y0, x0, valid}
+    __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDW];
+    __shared__ __attribute__((aligned(16))) int Pinfo[2][WBK][4];  // {byte offset of the pixel origin, y0, x0, valid}
 
     const int tid = threadIdx.x;
     const int lane_id = tid & 63, wave = tid >> 6;
@@ -1158,7 +1163,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     }
 
     // ---- loader geometry: thread -> (pixel quad, channel group + 32 * pass), see k_conv_wgrad_split
-    const int quad = tid & 7, grp0 = tid >> 3;
+    const int quad = tid % NQ, grp0 = tid / NQ;
     int d_off[DQ];       // byte offset of (pixel quad*4, channel group) inside a stage; -1: channels past Cout
     int x_tapoff[XQ];    // byte offset of (tap, ci) relative to a pixel origin
     int x_kh[XQ], x_kw[XQ], x_cq[XQ], d_cq[DQ];
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     // ---- pixel decode, 32 lanes, one stage ahead (carries instead of divisions inside the loop)
     int d_img = 0, d_oy = 0, d_ox = 0;
     unsigned d_p = p_lo + tid;
-    if (tid < WB_K) {
+    if (tid < WBK) {
         const unsigned pp = d_p < (unsigned)g.Mtot ? d_p : 0u;
         const unsigned t = pp / (unsigned)g.Wo;
         d_ox = (int)(pp - t * (unsigned)g.Wo);
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         d_img = (int)(im - img_lo);
     }
     auto decode = [&](int slot) {
-        if (tid < WB_K) {
+        if (tid < WBK) {
             const int y0 = d_oy * g.stride - g.pad, x0 = d_ox * g.stride - g.pad;
             int4 info;
             info.x = ((d_img * (int)ipix + y0 * g.W + x0) * (int)g.ldx) * 4;
@@ -1201,8 +1206,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             info.z = x0;
             info.w = d_p < p_hi ? 1 : 0;
             *reinterpret_cast<int4*>(&Pinfo[slot][tid][0]) = info;
-            d_p += WB_K;
-            d_ox += WB_K;
+            d_p += WBK;
+            d_ox += WBK;
             while (d_ox >= g.Wo) {
                 d_ox -= g.Wo;
                 if (++d_oy == g.Ho) {
@@ -1256,8 +1261,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             if (grp0 + GPP * q < DG) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    *reinterpret_cast<bf16x4*>(&Dh[(d_cq[q] + c) * LDB + quad * 4]) = pd[q][c][0];
-                    *reinterpret_cast<bf16x4*>(&Dl[(d_cq[q] + c) * LDB + quad * 4]) = pd[q][c][1];
+                    *reinterpret_cast<bf16x4*>(&Dh[(d_cq[q] + c) * LDW + quad * 4]) = pd[q][c][0];
+                    *reinterpret_cast<bf16x4*>(&Dl[(d_cq[q] + c) * LDW + quad * 4]) = pd[q][c][1];
                 }
             }
 #pragma unroll
@@ -1265,8 +1270,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             if (grp0 + GPP * q < XG) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    *reinterpret_cast<bf16x4*>(&Xh[(x_cq[q] + c) * LDB + quad * 4]) = px[q][c][0];
-                    *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDB + quad * 4]) = px[q][c][1];
+                    *reinterpret_cast<bf16x4*>(&Xh[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][0];
+                    *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][1];
                 }
             }
     };
@@ -1283,13 +1288,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
+            const int off = ((wm * TM + i) * 32 + r) * LDW + ks * 16 + 8 * h;
             ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
             al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
+            const int off = ((wn * TN + j) * 32 + r) * LDW + ks * 16 + 8 * h;
             bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
             bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
         }
@@ -1316,13 +1321,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
 #pragma unroll
     for (int q = 0; q < XQ; ++q) convert_quad(rx[q], px[q]);
     write_tiles();
-    load_tiles(p_lo + WB_K, 1);
+    load_tiles(p_lo + WBK, 1);
     decode(0);
     __syncthreads();
 
     int slot = 0;  // Pinfo slot of tile k+2
 #pragma unroll 1
-    for (unsigned p0 = p_lo; p0 < p_hi; p0 += WB_K) {
+    for (unsigned p0 = p_lo; p0 < p_hi; p0 += WBK) {
         mfma_group(0);
 #pragma unroll
         for (int q = 0; q < DQ; ++q) convert_quad(rd[q], pd[q]);
@@ -1343,7 +1348,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             __builtin_amdgcn_sched_group_barrier(0x002, VPG_X, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_tiles(p0 + 2 * WB_K, slot);
+#pragma unroll
+        for (int ks = 2; ks < WBK / 16; ++ks) mfma_group(ks);
+        load_tiles(p0 + 2 * WBK, slot);
         __syncthreads();
         write_tiles();
         decode(slot ^ 1);
@@ -2023,10 +2030,13 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
-    g.pix_per_split = snn_ceil_div(snn_ceil_div(g.Mtot, splitk), WB_K) * WB_K;
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);
     const WgradTile t = wgrad_tile(Cout, g.Ktot, g_backward_split && Cin % 4 == 0 && Cout % 4 == 0);
+    // small tiles (64 x 64, 32 x 128) run 64-pixel stages in the pipelined kernel (latency cover), the others 32
+    static const int wbk_small = getenv("SNN_WGRAD_WBK") ? atoi(getenv("SNN_WGRAD_WBK")) : 64;  // tuning aid
+    const int wbk = (t.id >= 4 && wbk_small == 64) ? 64 : 32;
+    g.pix_per_split = snn_ceil_div(snn_ceil_div(g.Mtot, splitk), wbk) * wbk;
     g.nimg = (int)N;
     // pipelined kernel: 32-bit byte offsets relative to the first image of a pixel split
     const int64_t span_pix = g.pix_per_split * (int64_t)stride * stride + 3 * (int64_t)H * W;
@@ -2042,8 +2052,11 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (pipe)                                                                                              \
-            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,    \
+        if (pipe && wbk == 64)                                                                                 \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64>), grid, dim3(kThreads), 0, st, x, dy, \
+                               workspace, g);                                                                  \
+        else if (pipe)                                                                                         \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32>), grid, dim3(kThreads), 0, st, x, dy, \
                                workspace, g);                                                                  \
         else if (vec && g_backward_split)                                                                      \
             hipLaunchKernelGGL((k_conv_wgrad_split<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,   \
