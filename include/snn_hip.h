@@ -256,6 +256,18 @@ int snn_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_
 int snn_events_to_frames(const int32_t* t_bin, const int32_t* x, const int32_t* y, const int32_t* p,
                          int64_t n_events, float* frames, int T, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- detection decode
+ * Tail of SODa.predict (models/soda.py:202-233): per anchor conf = max_k prob[k], class = argmax - 1 (background -1),
+ * box = offset_inverse(anchor, offsets) (utils/box.py:72-79, 102-119).  prob [A][K], offsets / anchors / boxes [A][4]. */
+int snn_detect_decode(const float* cls_prob, const float* offsets, const float* anchors, int A, int K,
+                      float* conf, int* cls, float* boxes, void* stream);
+/* Per-class greedy NMS (utils/box.py:82-99).  order[A]: anchor ids sorted by (class ascending, confidence descending);
+ * seg[num_classes + 1]: members of class c are order[seg[c] .. seg[c+1]).  kept[seg[c] ..) receives the kept ids of
+ * class c in keep order, nkept[c] their number; kept_flag[id] = 1 and kept_rank[id] = rank inside its class for kept
+ * anchors (both arrays must be zeroed by the caller).  One block per class; suppress when IoU > iou_threshold. */
+int snn_nms_sorted(const float* boxes, const int* order, const int* seg, int num_classes, float iou_threshold,
+                   int* kept, int* nkept, unsigned char* kept_flag, int* kept_rank, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

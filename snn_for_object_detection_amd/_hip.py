@@ -34,6 +34,8 @@ SIGNATURES = {
     "snn_nhwc_to_nchw": (c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "snn_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "snn_weight_transpose_batched": (c_int, [_P, _P, _P, _I, _P]),
+    "snn_detect_decode": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "snn_nms_sorted": (c_int, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
     "snn_set_backward_precision": (c_int, [_I]),
     "snn_get_backward_precision": (c_int, []),
     "snn_set_forward_precision": (c_int, [_I]),

@@ -1,7 +1,8 @@
 """Box utilities (mirror of the reference's ``utils/box.py``): IoU, offsets, NMS, detection decode.
 
-Tail of the step (tiny tensors: ``[B, A, C+1]`` / ``[B, A, 4]``); kept as torch tensor ops on the
-device for this round - SURVEY section 8f ranks the HIP versions as "next".
+Tail of the step (tiny tensors: ``[B, A, C+1]`` / ``[B, A, 4]``).  Target-side helpers are torch tensor ops;
+``multibox_detection`` on device tensors runs the HIP decode + greedy-NMS kernels of ``csrc/detect.hip`` (SURVEY
+section 8f rank 2), the loop below is the host form the fixtures pin.
 """
 
 import torch
@@ -65,10 +66,59 @@ def nms(boxes, scores, class_id, num_classes, iou_threshold) -> torch.Tensor:
     return torch.tensor(kept, device=boxes.device, dtype=torch.long)
 
 
+def _multibox_detection_device(cls_probs: torch.Tensor, offset_preds: torch.Tensor, anchors: torch.Tensor,
+                               nms_threshold: float, pos_threshold: float) -> torch.Tensor:
+    """Same result as the loop below, on the device and without host synchronisation: decode and greedy NMS are
+    HIP kernels (``csrc/detect.hip``), ordering uses torch's device sort / prefix sums as plumbing."""
+    from . import _hip
+    B, A, K = cls_probs.shape
+    dev = cls_probs.device
+    st = torch.cuda.current_stream().cuda_stream
+    probs = cls_probs.contiguous().float()
+    offs = offset_preds.contiguous().float()
+    anc = anchors.contiguous().float()
+    classes = torch.arange(K, device=dev, dtype=torch.int32)
+    out = []
+    for b in range(B):
+        conf = torch.empty(A, device=dev, dtype=torch.float32)
+        cls = torch.empty(A, device=dev, dtype=torch.int32)
+        boxes = torch.empty(A, 4, device=dev, dtype=torch.float32)
+        _hip.call("snn_detect_decode", probs[b].data_ptr(), offs[b].data_ptr(), anc.data_ptr(), A, K, conf.data_ptr(),
+                  cls.data_ptr(), boxes.data_ptr(), st)
+        # (class ascending, confidence descending); background (class -1) sorts first and is not a candidate
+        key = (cls + 1).double() * 2.0 - conf.double()
+        order = torch.argsort(key, stable=True).to(torch.int32)
+        counts = (cls.unsqueeze(1) + 1 == classes.unsqueeze(0)).sum(0)          # [K]: background, class 0, ...
+        seg = torch.cumsum(counts, 0).to(torch.int32).contiguous()              # seg[c] = first member of class c
+        kept = torch.empty(A, device=dev, dtype=torch.int32)
+        nkept = torch.zeros(K - 1, device=dev, dtype=torch.int32)
+        flag = torch.zeros(A, device=dev, dtype=torch.uint8)
+        rank = torch.zeros(A, device=dev, dtype=torch.int32)
+        _hip.call("snn_nms_sorted", boxes.data_ptr(), order.data_ptr(), seg.data_ptr(), K - 1, float(nms_threshold),
+                  kept.data_ptr(), nkept.data_ptr(), flag.data_ptr(), rank.data_ptr(), st)
+        # output order (utils/box.py:134-141): kept rows in class-then-score order, then the rest by anchor index
+        is_kept = flag.bool()
+        class_off = torch.cumsum(nkept, 0) - nkept
+        pos_kept = class_off[cls.clamp(min=0).long()].long() + rank.long()
+        not_kept = (~is_kept).long()
+        pos_rest = nkept.sum().long() + torch.cumsum(not_kept, 0) - not_kept
+        pos = torch.where(is_kept, pos_kept, pos_rest)
+        weak = conf < pos_threshold
+        class_out = torch.where(is_kept & ~weak, cls, torch.full_like(cls, -1)).float()
+        conf_out = torch.where(weak, 1 - conf, conf)
+        rows = torch.cat((class_out.unsqueeze(1), conf_out.unsqueeze(1), boxes), dim=1)
+        res = torch.empty_like(rows)
+        res.index_copy_(0, pos, rows)
+        out.append(res)
+    return torch.stack(out)
+
+
 def multibox_detection(cls_probs: torch.Tensor, offset_preds: torch.Tensor, anchors: torch.Tensor,
                        nms_threshold: float = 0.1, pos_threshold: float = 0.009999999) -> torch.Tensor:
     """``[B, A, 6]`` rows ``(class, conf, x1, y1, x2, y2)``; suppressed / background rows get class -1
     (utils/box.py:102-153)."""
+    if cls_probs.is_cuda:
+        return _multibox_detection_device(cls_probs, offset_preds, anchors, nms_threshold, pos_threshold)
     device = cls_probs.device
     _, num_anchors, num_classes = cls_probs.shape
     out = []

@@ -215,7 +215,6 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
                                                  bytes > 0xffffffffLL ? (int)0xffffffffu : (int)(unsigned)bytes,
                                                  0x00020000);
         rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, g.OC * g.KtotFull * 4, 0x00020000);
-        const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
         const int tw_n = DGRAD ? g.nkw : g.KW;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -112,6 +112,20 @@ def main():
     det = box.multibox_detection(probs.clone(), offp.clone(), anc_t)
     np.savez_compressed(os.path.join(OUT, "detect_nms.npz"), probs=probs.numpy(), offsets=offp.numpy(),
                         detections=det.numpy())
+
+    # ---- a mid-size NMS case (3 465 anchors, 3 classes + background, many overlapping confident boxes): pins the
+    #      device NMS kernel (chunked greedy suppression, several 256-candidate chunks per class)
+    per_map = []
+    for idx, (h, w) in enumerate([(15, 19), (8, 10), (4, 5)]):
+        g = anchors_mod.AnchorGenerator(sizes=sizes[idx].clone(), ratios=ratios.clone())
+        per_map.append(g(torch.zeros(1, 1, h, w)).clone())
+    anc_m = torch.cat(per_map)
+    A = anc_m.shape[0]
+    probs = torch.softmax(4 * torch.randn(2, A, 4, generator=gen), dim=2)
+    offp = 0.3 * torch.randn(2, A, 4, generator=gen)
+    det = box.multibox_detection(probs.clone(), offp.clone(), anc_m)
+    np.savez_compressed(os.path.join(OUT, "detect_nms_mid.npz"), anchors=anc_m.numpy(), probs=probs.numpy(),
+                        offsets=offp.numpy(), detections=det.numpy())
     print("golden vectors written to", OUT)
 
 
