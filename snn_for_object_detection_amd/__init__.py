@@ -12,6 +12,7 @@ raises if the library is missing - there is no CPU / eager fallback.
 
 from . import box, functional  # noqa: F401
 from .anchors import AnchorGenerator  # noqa: F401
+from .data import EventBatcher  # noqa: F401
 from .generator import BackboneGen, BlockGen, Head, HeadGen, ListGen, ListState, ModelGen, NeckGen  # noqa: F401
 from .layer_gen import *  # noqa: F401,F403
 from .roi import RoI  # noqa: F401

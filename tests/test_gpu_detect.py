@@ -84,3 +84,39 @@ def test_predict_streams_without_host_sync_in_decode(pkg):
     host[:, 2:] = torch.clamp(host[:, 2:], min=0.0, max=1.0)
     assert det.shape == host.shape
     assert torch.equal(det[:, 0].cpu(), host[:, 0]) and torch.allclose(det[:, 1:].cpu(), host[:, 1:], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- event feed (8f rank 1)
+def test_event_batcher_matches_oracle_and_feeds_the_model(pkg):
+    """Raw events -> device batch (pinned copy on a side stream + HIP scatter) equals the oracle voxelisation / collate
+    bit for bit, and the model consumes the channels-last batch without a layout pass."""
+    import numpy as np
+    from oracle import events as OE
+    T, B, H, W, step = 6, 3, 32, 48, 1000
+    rng = np.random.default_rng(5)
+    samples_np, samples_t, labels = [], [], []
+    for b in range(B):
+        n = 4000 + 500 * b
+        t0 = 10_000 * (b + 1)
+        t = rng.integers(t0 - 500, t0 + (T + 1) * step, n)      # some before t0, some past the window
+        x = rng.integers(0, W + 4, n)                            # some past the frame: clipped
+        y = rng.integers(0, H, n)
+        p = rng.integers(0, 2, n)
+        lab = rng.random((b + 1, 5)).astype(np.float32)
+        samples_np.append((OE.voxelize(t, x, y, p, t0, step, T, H, W), lab))
+        samples_t.append(tuple(torch.from_numpy(v).pin_memory() for v in (t, x, y, p)) + (t0,))
+        labels.append(torch.from_numpy(lab))
+    X_ref, lab_ref = OE.stack_batch(samples_np)
+    batcher = pkg.EventBatcher(T, H, W, step)
+    X, lab = batcher(samples_t, labels)
+    assert X.shape == (T, B, 2, H, W)
+    assert torch.equal(X.cpu(), torch.from_numpy(X_ref))
+    assert torch.equal(lab.cpu(), torch.from_numpy(lab_ref))
+    from snn_for_object_detection_amd import functional as HF
+    assert HF.is_channels_last(X)                               # no NCHW -> NHWC pass in front of the first conv
+    torch.manual_seed(1)
+    m = pkg.TinyYolo(num_classes=2, time_window=0).cuda().eval()
+    with torch.no_grad():
+        a = m(X)
+        b = m(torch.from_numpy(X_ref).cuda())
+    assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -77,3 +77,26 @@ def test_neuron_constants_match_oracle():
     p = S.functional.neuron_params()
     assert (p.c_mem, p.c_syn, p.v_leak, p.v_th, p.v_reset, p.alpha) == tuple(
         torch.tensor(neuron_constants(), dtype=torch.float32).tolist())
+
+
+def test_oracle_event_voxelisation_known_answers():
+    """oracle/events.py restates utils/datasets.py:403-435 / :127-135 (not importable: prophesee_toolbox is absent);
+    hand-checked cases pin it: binning, the t >= t0 filter, x clipping, flag-not-count, -1 label padding."""
+    import numpy as np
+    from oracle import events as OE
+    t = np.array([1000, 1999, 2000, 5999, 6000, 999, 2500, 2500], dtype=np.int64)
+    x = np.array([0, 3, 9, 2, 1, 1, 3, 3], dtype=np.int64)      # x = 9 lies outside a 6-wide frame: clipped to 5
+    y = np.array([0, 1, 2, 3, 0, 0, 1, 1], dtype=np.int64)
+    p = np.array([1, 0, 1, 0, 1, 1, 0, 0], dtype=np.int64)
+    f = OE.voxelize(t, x, y, p, t0_us=1000, time_step_us=1000, num_steps=5, height=4, width=6)
+    assert f.shape == (5, 2, 4, 6) and f.sum() == 5
+    assert f[0, 1, 0, 0] == 1 and f[0, 0, 1, 3] == 1             # t = 1000 and 1999 -> bin 0
+    assert f[1, 1, 2, 5] == 1                                     # t = 2000 -> bin 1, x clipped 9 -> 5
+    assert f[4, 0, 3, 2] == 1                                     # t = 5999 -> bin 4
+    assert f[1, 0, 1, 3] == 1                                     # the duplicate event is a flag, not a count
+    # t = 6000 is past the 5-step window, t = 999 precedes t0: both dropped
+    a = (f, np.array([[0, .1, .1, .5, .5]], dtype=np.float32))
+    b = (f * 0, np.array([[1, .2, .2, .6, .6], [0, .3, .3, .9, .9]], dtype=np.float32))
+    X, lab = OE.stack_batch([a, b])
+    assert X.shape == (5, 2, 2, 4, 6) and (X[:, 0] == f).all() and X[:, 1].sum() == 0
+    assert lab.shape == (2, 2, 5) and (lab[0, 1] == -1).all() and lab[1, 1, 0] == 0
