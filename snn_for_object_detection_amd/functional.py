@@ -360,6 +360,55 @@ def _slot_of(param) -> Optional[GradSlot]:
 
 
 # ------------------------------------------------------------------------------------------- conv
+def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st):
+    """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
+    (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
+    T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
+    dx = _new_cl((T, B), Cin, H, W, x)
+    addend, ld_add, addend2, ld_add2 = None, 0, None, 0
+    outer_fused = None
+    if acc is not None and acc[0].result is None and acc[0].deposits:
+        # another branch of the block already produced its gradient for this tensor: add it here
+        key, other = next(iter(acc[0].deposits.items()))
+        other = _raw_to_cl(other)
+        if tuple(other.shape) == tuple(dx.shape):
+            addend, ld_add = other.data_ptr(), cl_stride(other)
+            acc[0].fused[key] = acc[0].deposits.pop(key)
+    if (acc is not None and acc[0].result is None and not acc[0].deposits and acc[0].outer is not None
+            and FUSE_OUTER_ADDEND):
+        # the tensor is itself one alias of an enclosing fanout whose other consumer already deposited
+        # its gradient (bottleneck input: conv + residual shortcut + Dense pass-through): second addend
+        o_acc, o_key = acc[0].outer
+        if o_acc.result is None and len(o_acc.deposits) == 1 and o_key not in o_acc.deposits:
+            key2, other2 = next(iter(o_acc.deposits.items()))
+            other2 = _raw_to_cl(other2)
+            if tuple(other2.shape) == tuple(dx.shape):
+                addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
+                outer_fused = (o_acc, o_key, key2)
+    chained = False
+    if (acc is not None and acc[0].result is not None and addend is None and acc[1] not in acc[0].fused
+            and tuple(acc[0].result.shape) == tuple(dx.shape)):
+        # a sibling convolution already produced (its gradient + the fused deposits) for this tensor: add
+        # that here and become the accumulated result (two convolutions on one input: the C2f split)
+        prev = acc[0].result
+        addend, ld_add = prev.data_ptr(), cl_stride(prev)
+        chained = True
+    _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
+              Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, st)
+    if acc is not None and (acc[0].result is None or chained):
+        if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
+            acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
+            acc[0].outer[0].fused[acc[0].outer[1]] = dx    # fanout will hand back: the new total
+        acc[0].result = dx
+        acc[0].fused[acc[1]] = dx
+    if outer_fused is not None:
+        o_acc, o_key, key2 = outer_fused
+        o_acc.fused[key2] = o_acc.deposits.pop(key2)
+        o_acc.fused[o_key] = dx   # what the inner fanout will hand back for this alias
+        o_acc.result = dx
+    return dx
+
+
 class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
@@ -401,49 +450,7 @@ class _Conv2d(Function):
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
-            dx = _new_cl((T, B), Cin, H, W, x)
-            addend, ld_add, addend2, ld_add2 = None, 0, None, 0
-            acc = ctx.acc
-            outer_fused = None
-            if acc is not None and acc[0].result is None and acc[0].deposits:
-                # another branch of the block already produced its gradient for this tensor: add it here
-                key, other = next(iter(acc[0].deposits.items()))
-                other = _raw_to_cl(other)
-                if tuple(other.shape) == tuple(dx.shape):
-                    addend, ld_add = other.data_ptr(), cl_stride(other)
-                    acc[0].fused[key] = acc[0].deposits.pop(key)
-            if (acc is not None and acc[0].result is None and not acc[0].deposits and acc[0].outer is not None
-                    and FUSE_OUTER_ADDEND):
-                # the tensor is itself one alias of an enclosing fanout whose other consumer already deposited
-                # its gradient (bottleneck input: conv + residual shortcut + Dense pass-through): second addend
-                o_acc, o_key = acc[0].outer
-                if o_acc.result is None and len(o_acc.deposits) == 1 and o_key not in o_acc.deposits:
-                    key2, other2 = next(iter(o_acc.deposits.items()))
-                    other2 = _raw_to_cl(other2)
-                    if tuple(other2.shape) == tuple(dx.shape):
-                        addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
-                        outer_fused = (o_acc, o_key, key2)
-            chained = False
-            if (acc is not None and acc[0].result is not None and addend is None and acc[1] not in acc[0].fused
-                    and tuple(acc[0].result.shape) == tuple(dx.shape)):
-                # a sibling convolution already produced (its gradient + the fused deposits) for this tensor: add
-                # that here and become the accumulated result (two convolutions on one input: the C2f split)
-                prev = acc[0].result
-                addend, ld_add = prev.data_ptr(), cl_stride(prev)
-                chained = True
-            _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
-                      Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, st)
-            if acc is not None and (acc[0].result is None or chained):
-                if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
-                    acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
-                    acc[0].outer[0].fused[acc[0].outer[1]] = dx    # fanout will hand back: the new total
-                acc[0].result = dx
-                acc[0].fused[acc[1]] = dx
-            if outer_fused is not None:
-                o_acc, o_key, key2 = outer_fused
-                o_acc.fused[key2] = o_acc.deposits.pop(key2)
-                o_acc.fused[o_key] = dx   # what the inner fanout will hand back for this alias
-                o_acc.result = dx
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
             if ctx.slot is not None and USE_WGRAD_STREAM:
@@ -469,6 +476,86 @@ class _Conv2d(Function):
                           W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
         return dx, dw, None, None, None, None, None
+
+
+class _ComposedConv1x1(Function):
+    """``conv1x1(conv1x1(x, w1), w2)`` without the intermediate tensor (no Norm / neuron between the two: the C2f
+    entry ``Conv(c, 1)`` followed by the branch-opening ``Conv(c/2, 1)`` of ``models/tiny_yolo.py:76-82``).
+
+    Both maps are linear, so ``y = (w2 w1) x``.  Forward runs ONE 1x1 convolution with the composed weight; backward
+    needs neither ``conv(x, w1)`` nor its gradient: with ``G = sum_pixels gy x^T`` (one weight-gradient kernel),
+    ``dw2 = G w1^T``, ``dw1 = w2^T G`` and ``dx = conv^T(gy, w2 w1)``.  The composed weight is rounded once in fp32
+    (a re-association of the reference's two fp32 sums, same error level as any other summation order).
+    """
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, slot1, slot2, dest, acc):
+        _require_device(x, "conv2d input")
+        T, B, Cin, H, W = _dims5(x)
+        C1, C2 = w1.shape[0], w2.shape[0]
+        if w1.shape[1] != Cin or w2.shape[1] != C1 or tuple(w1.shape[2:]) != (1, 1) or tuple(w2.shape[2:]) != (1, 1):
+            raise RuntimeError("composed 1x1 convolution: weight shapes do not chain")
+        x = _raw_to_cl(x)
+        w1m = w1.detach().reshape(C1, Cin)
+        w2m = w2.detach().reshape(C2, C1)
+        wc = torch.mm(w2m, w1m).contiguous()                  # [C2, Cin] = OHWI of a 1x1 kernel
+        y = _out_tensor(dest, T, B, C2, H, W, x)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
+                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, _stream())
+        ctx.save_for_backward(x, w1m, w2m, wc)
+        ctx.geom = (T, B, Cin, H, W, C2, 1, 1, H, W, 1, 0)
+        ctx.c1 = C1
+        ctx.slots = (slot1, slot2)
+        ctx.acc = acc
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1m, w2m, wc = ctx.saved_tensors
+        T, B, Cin, H, W, C2 = ctx.geom[:6]
+        C1 = ctx.c1
+        gy = _raw_to_cl(gy)
+        ldg, ldx = cl_stride(gy), cl_stride(x)
+        st = _stream()
+        dx = dw1 = dw2 = None
+        if ctx.needs_input_grad[0]:
+            wct = wc.t().contiguous()                         # [Cin, C2] = transposed 1x1 weight
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wct, x, ctx.geom, st)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            slot1, slot2 = ctx.slots
+            slotted = slot1 is not None and slot2 is not None
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, C2, 1, 1)
+            side_ok = slotted and USE_WGRAD_STREAM
+            main = torch.cuda.current_stream()
+            stream = _side_stream(x.device) if side_ok else main
+            if side_ok:
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                ws = torch.empty((splitk, C2 * Cin), device=x.device, dtype=_F32)
+                G = torch.empty((C2, Cin), device=x.device, dtype=_F32)
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
+                          W, C2, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, stream.cuda_stream)
+                g2 = torch.mm(G, w1m.t())                     # [C2, C1]
+                g1 = torch.mm(w2m.t(), G)                     # [C1, Cin]
+                if slotted:
+                    for slot, g in ((slot2, g2), (slot1, g1)):
+                        view = slot.buf.view(g.shape)
+                        if slot.claim():
+                            view.add_(g)
+                        else:
+                            view.copy_(g)
+            if side_ok:
+                x.record_stream(stream)
+                gy.record_stream(stream)
+            if not slotted:
+                dw1, dw2 = g1.view(C1, Cin, 1, 1), g2.view(C2, C1, 1, 1)
+        return dx, dw1, dw2, None, None, None, None
+
+
+def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: Optional[Dest] = None) -> torch.Tensor:
+    seq, single = as_sequence(x)
+    y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq))
+    return y[0] if single else y
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,

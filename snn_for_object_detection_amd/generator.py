@@ -46,6 +46,11 @@ def _neuron_cell(layer: nn.Module) -> Optional[nn.Module]:
 #####################################################################
 #                         Block Generators                          #
 #####################################################################
+def _is_plain_1x1(layer) -> bool:
+    return (isinstance(layer, HipConv2d) and layer.kernel_size == (1, 1) and layer.stride == (1, 1)
+            and layer.padding == (0, 0) and layer.bias is None and layer.groups == 1)
+
+
 class BlockGen(nn.Module):
     """Builds a block from a (nested) configuration list and runs it (generator.py:35-198).
 
@@ -137,7 +142,13 @@ class BlockGen(nn.Module):
         while idx < n:
             layer = branch[idx]
             nxt = branch[idx + 1] if idx + 1 < n else None
-            if isinstance(layer, HipBatchNorm2d) and nxt is not None and _neuron_cell(nxt) is not None:
+            if (_is_plain_1x1(layer) and isinstance(nxt, BlockGen) and nxt._opens_with_1x1(layer.out_channels)
+                    and not os.environ.get("SNN_NO_COMPOSED_CONV")):
+                # Conv(c,1) feeding only the branch-opening Conv(.,1)s of the next block (the C2f entry): the two
+                # linear maps are composed and the intermediate tensor never exists (functional._ComposedConv1x1)
+                plan.append(("conv_block", idx, 2))
+                idx += 2
+            elif isinstance(layer, HipBatchNorm2d) and nxt is not None and _neuron_cell(nxt) is not None:
                 cell = _neuron_cell(nxt)
                 tanh_follows = (isinstance(cell, LICell) and not isinstance(nxt, StateStorage)
                                 and idx + 2 < n and isinstance(branch[idx + 2], HipTanh))
@@ -148,8 +159,17 @@ class BlockGen(nn.Module):
                 idx += 1
         return plan
 
+    def _opens_with_1x1(self, in_channels: int) -> bool:
+        """Every branch starts with a plain 1x1 convolution of the block input (and nothing else reads it)."""
+        if self.in_channels != in_channels or not len(self.net):
+            return False
+        for branch, plan in zip(self.net, self._plan):
+            if not plan or plan[0] != ("layer", 0, 1) or not _is_plain_1x1(branch[0]):
+                return False
+        return True
+
     # ------------------------------------------------------------------ execution
-    def forward(self, X: torch.Tensor, state: Optional[ListState] = None, dest=None, promise=None):
+    def forward(self, X: torch.Tensor, state: Optional[ListState] = None, dest=None, promise=None, pre_conv=None):
         """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence).
 
         ``dest`` / ``promise`` are internal (``functional.Dest`` / ``ConcatPromise``): on sequences the
@@ -206,8 +226,14 @@ class BlockGen(nn.Module):
                     if isinstance(holder, StateStorage):
                         holder.record(old, Y, new)
                     branch_state[idx + 1] = new
+                elif kind == "conv_block":
+                    blk = branch[idx + 1]
+                    Y, branch_state[idx + 1] = blk(Y, branch_state[idx + 1], dest=step_dest, promise=step_promise,
+                                                   pre_conv=layer)
                 elif isinstance(layer, BlockGen):
                     Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise)
+                elif isinstance(layer, HipConv2d) and pre_conv is not None and k == 0:
+                    Y = HF.composed_conv1x1(Y, pre_conv.weight, layer.weight, dest=step_dest)
                 elif isinstance(layer, HipConv2d):
                     Y = layer(Y, dest=step_dest)
                 elif isinstance(layer, (LIFCell, LICell, SLICell, SynapseCell)):

@@ -105,6 +105,26 @@ def test_dgrad_two_fused_addends(HF, hip_lib):
         assert torch.equal(only2, plain + a2)
 
 
+def test_composed_1x1_convolutions_equal_the_chain(HF):
+    """composed_conv1x1(x, w1, w2) == conv(conv(x, w1), w2) (values and all three gradients), without the middle tensor."""
+    torch.manual_seed(15)
+    T, B, Cin, C1, C2, H, W = 3, 2, 64, 64, 32, 9, 13
+    x = torch.randn(T, B, Cin, H, W)
+    w1 = torch.randn(C1, Cin, 1, 1) / Cin ** 0.5
+    w2 = torch.randn(C2, C1, 1, 1) / C1 ** 0.5
+    xr, w1r, w2r = (t.clone().double().requires_grad_() for t in (x, w1, w2))
+    yr = F.conv2d(F.conv2d(xr.flatten(0, 1), w1r), w2r)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    xd, w1d, w2d = (t.cuda().requires_grad_() for t in (x, w1, w2))
+    yd = HF.composed_conv1x1(xd, w1d, w2d)
+    yd.backward(g.float().view(yd.shape).cuda())
+    assert rel_err(yd.flatten(0, 1), yr) < 2e-6
+    assert rel_err(xd.grad, xr.grad) < 3e-5 and rel_err(w1d.grad, w1r.grad) < 3e-5 and rel_err(w2d.grad, w2r.grad) < 3e-5
+    with pytest.raises(RuntimeError):
+        HF.composed_conv1x1(xd, w2d, w1d)
+
+
 def test_shortcut_fused_into_lif_store(HF):
     """affine_neuron(addend=x): out = LIF(BN(y)) + x written by the scan kernel; d out / d x = identity."""
     torch.manual_seed(12)
