@@ -262,24 +262,12 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int voff = ((a_mask[j] >> tbit) & 1u) ? a_rel[j] + toff : -1;
-#if defined(SNN_ABL_NOLOAD)
-            ra[j] = f32x4{(float)voff, (float)k0n, 1.f, 2.f};
-#elif defined(SNN_ABL_HOT)
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (voff & 0x3ff0), 0, 0));
-#else
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
-#endif
         }
         const unsigned wb = (unsigned)wcol0 * 4u;
 #pragma unroll
         for (int j = 0; j < BROWS; ++j)
-#if defined(SNN_ABL_NOLOAD)
-            rb[j] = f32x4{(float)(b_rel[j] + wb), 1.f, 2.f, 3.f};
-#elif defined(SNN_ABL_HOT)
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)((b_rel[j] + wb) & 0x3ff0), 0, 0));
-#else
             rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(b_rel[j] + wb), 0, 0));
-#endif
     };
 
     auto load_tiles = [&](int k0) {
@@ -894,215 +882,11 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
         }
 }
 
-// bf16 x 3 form of the weight gradient (see k_conv_gather<..., SPLIT>): both operands are split into bf16 hi / lo
-// on the way into LDS.  K = pixels must be contiguous per lane for the bf16 MFMA, so every loader thread takes FOUR
-// consecutive pixels of its 4-channel group, transposes the 4x4 block in registers and writes [column][pixel]
-// images (80-byte rows, conflict-free ds_read_b128 fragments).
-template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_split(const float* __restrict__ x,
-                                                                                  const float* __restrict__ dy,
-                                                                                  float* __restrict__ ws, WgradGeom g) {
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int BMc = 32 * TM * WM, BNk = 32 * TN * WN;
-    constexpr int DG = BMc / 4, XG = BNk / 4;                                  // 4-channel groups per pixel row
-    // Loader thread -> (pixel quad = tid % 8, channel group = tid / 8 + 32 * pass): the 16 lanes of one LDS store
-    // group then write 8 quads (16 dwords) of two columns 4 apart, i.e. 16 dwords apart modulo the 32 banks -
-    // conflict-free.  (Consecutive lanes on consecutive channel groups, as before, put all 16 lanes on 2 bank
-    // pairs: measured 75 % of all LDS cycles were bank conflicts.)
-    constexpr int GPP = kThreads / 8;                                          // channel groups per pass
-    constexpr int DQ = (DG + GPP - 1) / GPP, XQ = (XG + GPP - 1) / GPP;        // passes per thread
-    __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDB];
-    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDB];
-    __shared__ int Pinfo[2][WB_K][4];
-
-    const int tid = threadIdx.x;
-    const int lane_id = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane_id & 31, h = lane_id >> 5;
-
-    const int tiles = g.tiles_m * g.tiles_n;
-    int L = blockIdx.x, z, tile;
-    if (g.splitk % 8 == 0) {
-        z = (L % 8) + 8 * (L / (8 * tiles));
-        tile = (L / 8) % tiles;
-    } else {
-        z = L / tiles;
-        tile = L % tiles;
-    }
-    const int co0 = (tile % g.tiles_m) * BMc;
-    const int kc0 = (tile / g.tiles_m) * BNk;
-    const int64_t p_lo = (int64_t)z * g.pix_per_split;
-    int64_t p_hi = p_lo + g.pix_per_split;
-    if (p_hi > g.Mtot) p_hi = g.Mtot;
-
-    const int quad = tid & 7, grp0 = tid >> 3;
-    int d_cq[DQ], x_cq[XQ], x_ci[XQ], x_kh[XQ], x_kw[XQ];
-    bool d_ok[DQ], x_ok[XQ];
-#pragma unroll
-    for (int q = 0; q < DQ; ++q) {
-        d_cq[q] = (grp0 + GPP * q) * 4;
-        d_ok[q] = (grp0 + GPP * q) < DG && (co0 + d_cq[q]) < g.Cout;
-    }
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-        x_cq[q] = (grp0 + GPP * q) * 4;
-        const int kc = kc0 + x_cq[q];
-        x_ok[q] = (grp0 + GPP * q) < XG && kc < g.Ktot;
-        const int tap = (x_ok[q] ? kc : 0) / g.Cin;
-        x_ci[q] = (x_ok[q] ? kc : 0) - tap * g.Cin;
-        x_kh[q] = tap / g.KW;
-        x_kw[q] = tap - x_kh[q] * g.KW;
-    }
-
-    int d_img = 0, d_oy = 0, d_ox = 0;
-    int64_t d_p = p_lo + tid;
-    if (tid < WB_K) {
-        int64_t pp = d_p < g.Mtot ? d_p : 0;
-        d_ox = (int)(pp % g.Wo);
-        int64_t t = pp / g.Wo;
-        d_oy = (int)(t % g.Ho);
-        d_img = (int)(t / g.Ho);
-    }
-    auto decode = [&](int slot) {
-        if (tid < WB_K) {
-            Pinfo[slot][tid][0] = d_p < p_hi ? d_img * g.H * g.W : 0;  // invalid pixels read (and discard) image 0
-            Pinfo[slot][tid][1] = d_oy * g.stride - g.pad;
-            Pinfo[slot][tid][2] = d_ox * g.stride - g.pad;
-            Pinfo[slot][tid][3] = d_p < p_hi ? 1 : 0;
-            d_p += WB_K;
-            d_ox += WB_K;
-            while (d_ox >= g.Wo) {
-                d_ox -= g.Wo;
-                if (++d_oy == g.Ho) {
-                    d_oy = 0;
-                    ++d_img;
-                }
-            }
-        }
-    };
-
-    f32x4 rd[DQ][4], rx[XQ][4];
-    auto load_tiles = [&](int64_t p0, int slot) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < DQ; ++q) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t p = p0 + quad * 4 + e;
-                const bool ok = (p < p_hi) & d_ok[q];
-                const int64_t pc = ok ? p : 0;
-                f32x4 v = *reinterpret_cast<const f32x4*>(dy + pc * g.lddy + (d_ok[q] ? co0 + d_cq[q] : 0));
-                rd[q][e] = ok ? v : zero;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = quad * 4 + e;
-            const int ibase = Pinfo[slot][row][0], y0 = Pinfo[slot][row][1], x0 = Pinfo[slot][row][2];
-            const bool pok = Pinfo[slot][row][3] != 0;
-#pragma unroll
-            for (int q = 0; q < XQ; ++q) {
-                const int iy = y0 + x_kh[q], ix = x0 + x_kw[q];
-                const bool ok = pok & x_ok[q] & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-                const int iyc = min(max(iy, 0), g.H - 1), ixc = min(max(ix, 0), g.W - 1);
-                f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(ibase + iyc * g.W + ixc) * g.ldx + x_ci[q]);
-                rx[q][e] = ok ? v : zero;
-            }
-        }
-    };
-    // 4 pixels x 4 channels -> per channel the 4 pixels as bf16 hi / lo, 8 bytes each
-    auto store_quad = [&](const f32x4 (&v)[4], __bf16* hi_img, __bf16* lo_img, int col0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)v[e][c];
-                lo[e] = (__bf16)(v[e][c] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4*>(&hi_img[(col0 + c) * LDB + quad * 4]) = hi;
-            *reinterpret_cast<bf16x4*>(&lo_img[(col0 + c) * LDB + quad * 4]) = lo;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int q = 0; q < DQ; ++q)
-            if (grp0 + GPP * q < DG) store_quad(rd[q], Dh, Dl, d_cq[q]);
-#pragma unroll
-        for (int q = 0; q < XQ; ++q)
-            if (grp0 + GPP * q < XG) store_quad(rx[q], Xh, Xl, x_cq[q]);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    decode(0);
-    __syncthreads();
-    load_tiles(p_lo, 0);
-    decode(1);
-    store_tiles();
-    __syncthreads();
-
-    int slot = 1;
-#pragma unroll 1
-    for (int64_t p0 = p_lo; p0 < p_hi; p0 += WB_K) {
-        load_tiles(p0 + WB_K, slot);
-        decode(slot ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < WB_K / 16; ++ks) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
-                ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
-        slot ^= 1;
-    }
-
-    float* slab = ws + (int64_t)z * g.Cout * (int64_t)g.Ktot;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int kcol = kc0 + (wn * TN + j) * 32 + r;
-            if (kcol >= g.Ktot) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = co0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < g.Cout) slab[(int64_t)co * g.Ktot + kcol] = acc[i][j][e];
-            }
-        }
-}
-
-// Pipelined form of k_conv_wgrad_split (host-checked: one pixel split of x spans < 2 GiB, so 32-bit byte offsets
-// relative to the split's first image address every gathered pixel).  Same arithmetic and accumulation order as
-// k_conv_wgrad_split; what changes is WHEN things happen, as in the pipelined k_conv_gather loop:
+// bf16 x 3 weight gradient (see k_conv_gather<..., SPLIT>): both operands are split into bf16 hi / lo on the way into
+// LDS.  K = pixels must be contiguous per lane for the bf16 MFMA, so every loader thread takes FOUR consecutive
+// pixels of its 4-channel group, transposes the 4x4 block in registers and writes [column][pixel] images.
+// Host-checked: one pixel split of x spans < 2 GiB, so 32-bit byte offsets relative to the split's first image
+// address every gathered pixel (larger problems take the exact-fp32 kernel above).  Pipelined like k_conv_gather:
 //   * raw buffer loads with hardware range checking (offset 0xFFFFFFFF -> zeros): no clamps, selects or 64-bit
 //     address arithmetic; dy rows past the split's last pixel fall off the end of the buffer resource;
 //   * tile k+1 is converted to its bf16 pieces in the shadow of tile k's MFMAs and the loads of tile k+2 are
@@ -1161,7 +945,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
                                                  xbytes > 0x7fffffffLL ? 0x7fffffff : (xbytes < 0 ? 0 : (int)xbytes), 0x00020000);
     }
 
-    // ---- loader geometry: thread -> (pixel quad, channel group + 32 * pass), see k_conv_wgrad_split
+    // ---- loader geometry: thread -> (pixel quad = tid % NQ, channel group = tid / NQ + GPP * pass): the 16 lanes of
+    // one LDS store group write whole 16-dword runs of a column - conflict-free.  (Consecutive lanes on consecutive
+    // channel groups put all 16 lanes on 2 bank pairs: measured 75 % of all LDS cycles were bank conflicts.)
     const int quad = tid % NQ, grp0 = tid / NQ;
     int d_off[DQ];       // byte offset of (pixel quad*4, channel group) inside a stage; -1: channels past Cout
     int x_tapoff[XQ];    // byte offset of (tap, ci) relative to a pixel origin
@@ -2056,9 +1842,6 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
                                workspace, g);                                                                  \
         else if (pipe)                                                                                         \
             hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32>), grid, dim3(kThreads), 0, st, x, dy, \
-                               workspace, g);                                                                  \
-        else if (vec && g_backward_split)                                                                      \
-            hipLaunchKernelGGL((k_conv_wgrad_split<TM_, TN_, WM_, WN_>), grid, dim3(kThreads), 0, st, x, dy,   \
                                workspace, g);                                                                  \
         else if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
                                     dy, workspace, g);                                                         \
