@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 3
+#define SNN_ABI_VERSION 4
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -194,6 +194,22 @@ int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const flo
                           const float* alpha, const float* beta, int apply_scale,
                           float* gx, float* g_v0, float* g_i0, double* sums,
                           int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+
+/* Memory-saving LIF pair (same results, bit for bit, as the two calls above with neuron = SNN_NEURON_LIF).  Instead
+ * of vd[t] for every step, the forward stores the state (v, i) BEFORE every K-th step, K = snn_lif_ckpt_interval():
+ *   ckpt[ceil(T/K)][2][M][C]   (2*ceil(T/K)/T of the per-step buffer: half at K = 4)
+ * and the backward scan re-runs the K forward steps of a chunk from its checkpoint (it needs y and alpha/beta for
+ * that) before walking the chunk in reverse.  An opt-in memory lever for 1280x720-class inputs
+ * (functional.LIF_CHECKPOINT_BYTES); speed-neutral. */
+int snn_lif_ckpt_interval(void);
+int snn_lif_fwd_ckpt(const float* y, int64_t ldy, const float* alpha, const float* beta,
+                     const float* v0, const float* i0, float* out, int64_t ldo,
+                     const float* addend, int64_t ld_addend, float* vT, float* iT, float* ckpt,
+                     int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+int snn_lif_bwd_ckpt(const float* g_out, int64_t ldg, const float* ckpt, const float* y, int64_t ldy,
+                     const float* g_vT, const float* g_iT, const float* alpha, const float* beta, int apply_scale,
+                     float* gx, float* g_v0, float* g_i0, double* sums,
+                     int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
 
 /* BatchNorm backward, second phase.  From the partial sums: per-(t,c)
  *   dy = A*gx + Bc*y + Cc,  A = alpha, Bc = -alpha*invstd*s2, Cc = -alpha*s1 + alpha*invstd*mean*s2,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NeuronParams(Structure):
@@ -54,6 +54,11 @@ SIGNATURES = {
     "snn_bn_bwd_coef": (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),
+    "snn_lif_ckpt_interval": (c_int, []),
+    "snn_lif_fwd_ckpt": (c_int, [_P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I,
+                                 POINTER(NeuronParams), _P]),
+    "snn_lif_bwd_ckpt": (c_int, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
+                                 POINTER(NeuronParams), _P]),
     "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),
     "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _P]),

@@ -251,7 +251,12 @@ __global__ void k_bn_running_update(const float* __restrict__ mean, const double
 // ------------------------------------------------------------------------------------------
 // Forward scan
 // ------------------------------------------------------------------------------------------
-template <int NEURON, int VEC, bool SAVE>
+// SAVE: 0 nothing for the backward pass; 1 the per-step state (vdec); 2 (LIF) the state (v, i) BEFORE every kCkpt-th step
+// into vdec = ckpt[chunk][2][M][C]: the backward scan recomputes the steps of a chunk from it (k_lif_bwd_ckpt) instead
+// of reading one saved value per step.  Half the saved-state memory of mode 1 at the same speed (forward faster,
+// backward slower by about as much); opt-in from functional.LIF_CHECKPOINT_BYTES.
+constexpr int kCkpt = 4;
+template <int NEURON, int VEC, int SAVE>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     const float* __restrict__ y, int64_t ldy, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ v0, const float* __restrict__ i0, float* __restrict__ out, int64_t ldo,
@@ -279,6 +284,11 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
         }
         for (int t = 0; t < T; ++t) {
             const int64_t row = (int64_t)t * M + m;
+            if (SAVE == 2 && NEURON == SNN_NEURON_LIF && (t % kCkpt) == 0) {
+                float* ck = vdec + ((int64_t)(t / kCkpt) * 2 * M + m) * C + c;
+                Vec<VEC>::store(ck, v);
+                Vec<VEC>::store(ck + M * C, i);
+            }
             V x = Vec<VEC>::load(y + row * ldy + c);
             if (alpha) {
                 V a = Vec<VEC>::load(alpha + (int64_t)t * C + c);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                 for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(ad, j);
             }
             Vec<VEC>::store(out + row * ldo + c, o);
-            if (SAVE && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
+            if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
                 Vec<VEC>::store(vdec + row * C + c, vd);
         }
         if (NEURON != SNN_NEURON_NONE) {
@@ -624,6 +634,220 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     }
 }
 
+// LIF backward scan from checkpoints (forward SAVE mode 2).  Same grid, block roles, reduction order and outputs as
+// k_affine_neuron_bwd<LIF>; per chunk of kCkpt steps (last chunk first) a thread re-runs the forward recurrence from
+// the chunk's saved (v, i) - the very expressions of k_affine_neuron_fwd, so the recomputed membrane values are the
+// forward's bit for bit - and then walks the chunk backwards.  The next chunk's loads are issued before the current
+// chunk is processed.
+constexpr int kCkptNP = 2;
+template <int VEC, int MODE>
+__global__ __launch_bounds__(kThreads) void k_lif_bwd_ckpt(
+    const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ ckpt, const float* __restrict__ y,
+    int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
+    const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
+    float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p) {
+    typedef typename Vec<VEC>::type V;
+    constexpr int NP = kCkptNP;
+    constexpr int K = kCkpt;
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int cv = C / VEC;
+    const int P = kThreads / cvb;
+    const int tid = threadIdx.x;
+    const int cgl = tid % cvb, ps = tid / cvb;
+    const int cg = blockIdx.y * cvb + cgl;
+    const int cb = cvb * VEC;
+    const bool lane_ok = (ps < P) && (cg < cv);
+    const int c = lane_ok ? cg * VEC : 0;
+    const int wave = tid >> 6;
+    if (MODE != 0) {
+        const int n = (MODE == 1 ? kWaves : 1) * T * cb * 2;
+        for (int k = tid; k < n; k += kThreads) red[k] = 0.0f;
+        __syncthreads();
+    }
+    const float one_m_cmem = 1.0f - p.c_mem;
+    const float one_p_csyn = 1.0f + p.c_syn;
+    const int64_t rows = (M + P - 1) / P;
+    const int64_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t row_lo = (int64_t)blockIdx.x * rpb;
+    const int64_t row_hi = row_lo + rpb < rows ? row_lo + rpb : rows;
+    const int nchunks = (T + K - 1) / K;
+    struct Set {
+        V v[NP], i[NP], yv[K][NP], go[K][NP];
+    };
+    for (int64_t rb = row_lo; rb < row_hi; rb += NP) {
+        int64_t mq[NP];
+        bool ok[NP];
+        V gv[NP], gi[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            mq[q] = (rb + q) * P + ps;
+            ok[q] = lane_ok && rb + q < row_hi && mq[q] < M;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) lane<VEC>(gv[q], j) = lane<VEC>(gi[q], j) = 0.0f;
+            if (ok[q]) {
+                if (g_vT) gv[q] = Vec<VEC>::load(g_vT + mq[q] * C + c);
+                if (g_iT) gi[q] = Vec<VEC>::load(g_iT + mq[q] * C + c);
+            }
+        }
+        auto fetch = [&](int ch, Set& s) {
+            const int t0 = ch * K;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (!ok[q]) continue;
+                const float* ck = ckpt + ((int64_t)ch * 2 * M + mq[q]) * C + c;
+                s.v[q] = Vec<VEC>::load(ck);
+                s.i[q] = Vec<VEC>::load(ck + M * C);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (t0 + k < T) {
+                        const int64_t row = (int64_t)(t0 + k) * M + mq[q];
+                        s.yv[k][q] = Vec<VEC>::load(y + row * ldy + c);
+                        s.go[k][q] = Vec<VEC>::load(g_out + row * ldg + c);
+                    }
+                }
+            }
+        };
+        auto process = [&](int ch, Set& s) {
+            const int t0 = ch * K;
+            V vd[K][NP];
+            // forward recurrence of the chunk (k_affine_neuron_fwd, LIF branch)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (t0 + k >= T) continue;
+                V a1, b1;
+                if (alpha) {
+                    a1 = Vec<VEC>::load(alpha + (int64_t)(t0 + k) * C + c);
+                    b1 = Vec<VEC>::load(beta + (int64_t)(t0 + k) * C + c);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float xj = lane<VEC>(s.yv[k][q], j);
+                        if (alpha) xj = xj * lane<VEC>(a1, j) + lane<VEC>(b1, j);
+                        const float vj = lane<VEC>(s.v[q], j), ij = lane<VEC>(s.i[q], j);
+                        const float i_new = ij + xj;
+                        const float dv = p.c_mem * ((p.v_leak - vj) + i_new);
+                        const float v_dec = vj + dv;
+                        const float di = p.c_syn * i_new;
+                        lane<VEC>(s.i[q], j) = i_new + di;
+                        const float u = v_dec - p.v_th;
+                        const float z = (u > 0.0f) ? 1.0f : 0.0f;
+                        lane<VEC>(s.v[q], j) = (1.0f - z) * v_dec + z * p.v_reset;
+                        lane<VEC>(vd[k][q], j) = v_dec;
+                    }
+            }
+            // reverse-time walk of the chunk (k_affine_neuron_bwd, LIF branch)
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const int t = t0 + k;
+                if (t >= T) continue;
+                float s1[VEC], s2[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (!ok[q]) continue;
+                    const int64_t row = (int64_t)t * M + mq[q];
+                    V g;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float goj = lane<VEC>(s.go[k][q], j);
+                        const float vdj = lane<VEC>(vd[k][q], j);
+                        const float u = vdj - p.v_th;
+                        const float z = (u > 0.0f) ? 1.0f : 0.0f;
+                        const float den = p.alpha * fabsf(u) + 1.0f;
+                        const float sg = 1.0f / (den * den);
+                        const float gvj = lane<VEC>(gv[q], j);
+                        const float gz = goj + gvj * (p.v_reset - vdj);
+                        const float g_vd = gvj * (1.0f - z) + gz * sg;
+                        const float g_in = p.c_mem * g_vd + lane<VEC>(gi[q], j) * one_p_csyn;
+                        lane<VEC>(gv[q], j) = g_vd * one_m_cmem;
+                        lane<VEC>(gi[q], j) = g_in;
+                        lane<VEC>(g, j) = g_in;
+                        if (MODE != 0) {
+                            s1[j] += g_in;
+                            s2[j] += g_in * lane<VEC>(s.yv[k][q], j);
+                        }
+                    }
+                    if (apply_scale) {
+                        V sc = Vec<VEC>::load(alpha + (int64_t)t * C + c);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
+                    }
+                    Vec<VEC>::store(gx + row * C + c, g);
+                }
+                if (MODE == 1) {
+                    if (cvb < 64) {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j)
+                            for (int stride = cvb; stride < 64; stride <<= 1) {
+                                s1[j] += __shfl_xor(s1[j], stride, 64);
+                                s2[j] += __shfl_xor(s2[j], stride, 64);
+                            }
+                    }
+                    if ((cvb >= 64 || (tid & 63) < cvb) && lane_ok) {
+                        float* r = red + (((int64_t)wave * T + t) * cb + cgl * VEC) * 2;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            r[j * 2 + 0] += s1[j];
+                            r[j * 2 + 1] += s2[j];
+                        }
+                    }
+                } else if (MODE == 2) {
+                    if (lane_ok) {
+                        float* r = red + ((int64_t)t * cb + cgl * VEC) * 2;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            atomicAdd(r + j * 2 + 0, s1[j]);
+                            atomicAdd(r + j * 2 + 1, s2[j]);
+                        }
+                    }
+                }
+            }
+        };
+        Set A, B;
+        fetch(nchunks - 1, A);
+        for (int ch = nchunks - 1; ch >= 0; ch -= 2) {
+            if (ch >= 1) fetch(ch - 1, B);
+            process(ch, A);
+            if (ch >= 1) {
+                if (ch >= 2) fetch(ch - 2, A);
+                process(ch - 1, B);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (!ok[q]) continue;
+            if (g_v0) Vec<VEC>::store(g_v0 + mq[q] * C + c, gv[q]);
+            if (g_i0) Vec<VEC>::store(g_i0 + mq[q] * C + c, gi[q]);
+        }
+    }
+    if (MODE != 0) {
+        __syncthreads();
+        float* dst = reinterpret_cast<float*>(sums) + (int64_t)blockIdx.x * T * C * 2;
+        const int c_lo = blockIdx.y * cb;
+        for (int k = tid; k < T * cb; k += kThreads) {
+            int t = k / cb, cl = k % cb;
+            if (c_lo + cl < C) {
+                float a = 0.0f, b = 0.0f;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) {
+                        a += red[((int64_t)w * T * cb + k) * 2 + 0];
+                        b += red[((int64_t)w * T * cb + k) * 2 + 1];
+                    }
+                } else {
+                    a = red[k * 2 + 0];
+                    b = red[k * 2 + 1];
+                }
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 0] = a;
+                dst[((int64_t)t * C + c_lo + cl) * 2 + 1] = b;
+            }
+        }
+    }
+}
+
 // reduce block partials -> raw[t][c] = (sum gx, sum gx*y).  32 lanes per (t,c): lane k sums blocks k, k+32, ...
 // then a fixed xor tree combines the lanes.  `raw` must not alias the partial buffer (fp32 partials, fp64 result).
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict__ sums_, int gx_blocks, int T, int C,
@@ -857,10 +1081,10 @@ extern "C" int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total
                                y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p); \
     } while (0)
 
-extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta,
-                                     const float* v0, const float* i0, float* out, int64_t ldo, const float* addend,
-                                     int64_t ld_addend, float* vT, float* iT, float* vdec, int T, int64_t M, int C,
-                                     const snn_neuron_params* p, void* stream) {
+static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta, const float* v0,
+                      const float* i0, float* out, int64_t ldo, const float* addend, int64_t ld_addend, float* vT,
+                      float* iT, float* vdec, int ckpt_mode, int T, int64_t M, int C, const snn_neuron_params* p,
+                      void* stream) {
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
     SNN_REQUIRE(!addend || (ld_addend >= C && neuron != SNN_NEURON_LI_TANH),
                 "snn_affine_neuron_fwd: addend needs ld_addend >= C and is not allowed with LI_TANH");
@@ -880,24 +1104,44 @@ extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, co
     int64_t blocks = snn_ceil_div(total, kThreads * per_thread);
     dim3 grid((unsigned)blocks);
     switch (neuron) {
-        case SNN_NEURON_NONE: SNN_DISPATCH_FWD(SNN_NEURON_NONE, false); break;
+        case SNN_NEURON_NONE: SNN_DISPATCH_FWD(SNN_NEURON_NONE, 0); break;
         case SNN_NEURON_LIF:
-            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_LIF, true);
-            else SNN_DISPATCH_FWD(SNN_NEURON_LIF, false);
+            if (vdec && ckpt_mode) SNN_DISPATCH_FWD(SNN_NEURON_LIF, 2);
+            else if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_LIF, 1);
+            else SNN_DISPATCH_FWD(SNN_NEURON_LIF, 0);
             break;
-        case SNN_NEURON_LI: SNN_DISPATCH_FWD(SNN_NEURON_LI, false); break;
-        case SNN_NEURON_LI_TANH: SNN_DISPATCH_FWD(SNN_NEURON_LI_TANH, false); break;
+        case SNN_NEURON_LI: SNN_DISPATCH_FWD(SNN_NEURON_LI, 0); break;
+        case SNN_NEURON_LI_TANH: SNN_DISPATCH_FWD(SNN_NEURON_LI_TANH, 0); break;
         case SNN_NEURON_SLI:
-            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SLI, true);
-            else SNN_DISPATCH_FWD(SNN_NEURON_SLI, false);
+            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SLI, 1);
+            else SNN_DISPATCH_FWD(SNN_NEURON_SLI, 0);
             break;
         default:
-            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, true);
-            else SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, false);
+            if (vdec) SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, 1);
+            else SNN_DISPATCH_FWD(SNN_NEURON_SYNAPSE, 0);
             break;
     }
     SNN_CHECK_LAUNCH("snn_affine_neuron_fwd");
     return 0;
+}
+
+extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta,
+                                     const float* v0, const float* i0, float* out, int64_t ldo, const float* addend,
+                                     int64_t ld_addend, float* vT, float* iT, float* vdec, int T, int64_t M, int C,
+                                     const snn_neuron_params* p, void* stream) {
+    return neuron_fwd(neuron, y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, 0, T, M, C, p,
+                      stream);
+}
+
+extern "C" int snn_lif_ckpt_interval(void) { return kCkpt; }
+
+extern "C" int snn_lif_fwd_ckpt(const float* y, int64_t ldy, const float* alpha, const float* beta, const float* v0,
+                                const float* i0, float* out, int64_t ldo, const float* addend, int64_t ld_addend,
+                                float* vT, float* iT, float* ckpt, int T, int64_t M, int C, const snn_neuron_params* p,
+                                void* stream) {
+    SNN_REQUIRE(ckpt, "snn_lif_fwd_ckpt: null checkpoint buffer");
+    return neuron_fwd(SNN_NEURON_LIF, y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, ckpt, 1, T, M,
+                      C, p, stream);
 }
 
 extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
@@ -955,6 +1199,41 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
         default: SNN_DISPATCH_BWD(SNN_NEURON_SYNAPSE); break;
     }
     SNN_CHECK_LAUNCH("snn_affine_neuron_bwd");
+    return 0;
+}
+
+#define SNN_LAUNCH_CKPT(VEC_, MODE_)                                                                              \
+    hipLaunchKernelGGL((k_lif_bwd_ckpt<VEC_, MODE_>), grid, dim3(kThreads), pl.lds_bytes, (hipStream_t)stream, g_out, \
+                       ldg, ckpt, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, g_v0, g_i0, sums, T, M, C, pl.cvb, \
+                       *p)
+
+// LIF backward from the checkpoints of snn_lif_fwd_ckpt; sums / outputs exactly as snn_affine_neuron_bwd(LIF)
+extern "C" int snn_lif_bwd_ckpt(const float* g_out, int64_t ldg, const float* ckpt, const float* y, int64_t ldy,
+                                const float* g_vT, const float* g_iT, const float* alpha, const float* beta,
+                                int apply_scale, float* gx, float* g_v0, float* g_i0, double* sums, int T, int64_t M,
+                                int C, const snn_neuron_params* p, void* stream) {
+    SNN_REQUIRE(g_out && gx && p && ckpt && y, "snn_lif_bwd_ckpt: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C && ldy >= C, "snn_lif_bwd_ckpt: bad shape");
+    SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_lif_bwd_ckpt: alpha/beta must come together");
+    SNN_REQUIRE(!apply_scale || alpha, "snn_lif_bwd_ckpt: apply_scale needs alpha");
+    BwdPlan pl = bwd_plan(T, M, C, sums != nullptr);
+    if (pl.vec == 4) {
+        bool ok = ldg % 4 == 0 && ldy % 4 == 0 && aligned16(g_out) && aligned16(ckpt) && aligned16(y) &&
+                  aligned16(g_vT) && aligned16(g_iT) && aligned16(alpha) && aligned16(beta) && aligned16(gx) &&
+                  aligned16(g_v0) && aligned16(g_i0);
+        SNN_REQUIRE(ok, "snn_lif_bwd_ckpt: buffers must be 16-byte aligned when C%%4==0");
+    }
+    dim3 grid(pl.gx, pl.gy);
+    if (pl.vec == 4) {
+        if (pl.mode == 0) SNN_LAUNCH_CKPT(4, 0);
+        else if (pl.mode == 1) SNN_LAUNCH_CKPT(4, 1);
+        else SNN_LAUNCH_CKPT(4, 2);
+    } else {
+        if (pl.mode == 0) SNN_LAUNCH_CKPT(1, 0);
+        else if (pl.mode == 1) SNN_LAUNCH_CKPT(1, 1);
+        else SNN_LAUNCH_CKPT(1, 2);
+    }
+    SNN_CHECK_LAUNCH("snn_lif_bwd_ckpt");
     return 0;
 }
 

@@ -9,6 +9,7 @@ of the hot path happens in ``libsnn_hip.so``.  No CPU / eager fallback exists: t
 not on a HIP device raise.
 """
 
+import collections
 import os
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
@@ -87,8 +88,30 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# Operands of a side-stream kernel are kept alive HERE until the main stream has waited for that kernel, instead of
+# being handed to ``Tensor.record_stream``: a record_stream'ed block returns to the caching allocator only once the
+# GPU has really passed the event, and the host enqueues a whole backward pass ahead of the GPU - so every dy of the
+# pass stayed reserved at once (257 GiB reserved for 113 GiB live on the 1280x720 B=4 step, and an allocator that
+# frees and re-mallocs its cache each step from B=6 on).  Released this way the blocks are recycled in stream order.
+_SIDE_PENDING = collections.deque()   # (event recorded on the side stream, tensors its kernels read)
+
+
+def _side_retire(main, keep: int) -> None:
+    """Main stream waits for all but the ``keep`` most recent side-stream launches and drops their operands."""
+    while len(_SIDE_PENDING) > keep:
+        ev, _tensors = _SIDE_PENDING.popleft()
+        main.wait_event(ev)
+
+
+def _side_hold(side, *tensors) -> None:
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _SIDE_PENDING.append((ev, tensors))
+
+
 def wgrad_stream_sync() -> None:
     """Make the current stream wait for every weight-gradient kernel queued on the side stream."""
+    _SIDE_PENDING.clear()
     for dev, st in _SIDE_STREAMS.items():
         torch.cuda.current_stream(dev).wait_stream(st)
 
@@ -457,14 +480,14 @@ class _Conv2d(Function):
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                _side_retire(main, 1)   # the weight gradient before the previous one is joined; its operands go
                 side.wait_stream(main)  # gy (and every earlier use of the slot) is complete
                 with torch.cuda.stream(side):
                     ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                     _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(),
                               T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(),
                               splitk, side.cuda_stream)
-                x.record_stream(side)
-                gy.record_stream(side)
+                _side_hold(side, x, gy)
             elif ctx.slot is not None:
                 ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(), T * B,
@@ -529,6 +552,7 @@ class _ComposedConv1x1(Function):
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main
             if side_ok:
+                _side_retire(main, 1)
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 ws = torch.empty((splitk, C2 * Cin), device=x.device, dtype=_F32)
@@ -545,8 +569,7 @@ class _ComposedConv1x1(Function):
                         else:
                             view.copy_(g)
             if side_ok:
-                x.record_stream(stream)
-                gy.record_stream(stream)
+                _side_hold(stream, x, gy)
             if not slotted:
                 dw1, dw2 = g1.view(C1, Cin, 1, 1), g2.view(C2, C1, 1, 1)
         return dx, dw1, dw2, None, None, None, None
@@ -581,6 +604,14 @@ class SynapseState(NamedTuple):
 
 
 _SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
+
+# Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores
+# checkpoints of (v, i) every snn_lif_ckpt_interval() steps instead and recomputes in the backward scan
+# (snn_lif_fwd_ckpt / snn_lif_bwd_ckpt: bit-identical results, half the saved-state memory, speed-neutral).
+# None (default) = never, 0 = every LIF layer.  Measured on 1280x720 B=4 T=32: 125 -> 113 GiB live.  Off by default
+# because the half-size buffers fragment torch's caching allocator once the live set approaches the whole HBM
+# (B=8: 222 GiB live but 287 GiB reserved and a thrashing allocator, against 250 GiB live at full speed without).
+LIF_CHECKPOINT_BYTES: Optional[int] = None
 
 
 class _AffineNeuron(Function):
@@ -645,8 +676,15 @@ class _AffineNeuron(Function):
         iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
         need_grad = any(ctx.needs_input_grad[:5])
         vdec = None
+        ckpt = False
         if neuron in _SAVES_STEP and need_grad:
-            vdec = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
+            ckpt = (neuron == _hip.NEURON_LIF and LIF_CHECKPOINT_BYTES is not None
+                    and T * M * C * 4 >= LIF_CHECKPOINT_BYTES)
+            if ckpt:
+                k = _hip.query("snn_lif_ckpt_interval")
+                vdec = torch.empty(((T + k - 1) // k, 2, B, H, W, C), device=dev, dtype=_F32)
+            else:
+                vdec = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
         if v0 is not None:
             v0 = _expand_state(v0, (B, C, H, W), dev)
         if i0 is not None:
@@ -661,9 +699,15 @@ class _AffineNeuron(Function):
             if tuple(addend.shape) != (T, B, C, H, W):
                 raise RuntimeError("Residual merge: branch outputs differ in shape")
             ad_ptr, ld_ad = addend.data_ptr(), cl_stride(addend)
-        _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
-                  out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
-                  _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params, st)
+        if ckpt:
+            _hip.call("snn_lif_fwd_ckpt", y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
+                      out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT), _ptr(iT), vdec.data_ptr(), T, M, C,
+                      params, st)
+        else:
+            _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
+                      out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
+                      _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params, st)
+        ctx.ckpt = ckpt
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
         ctx.sync_group = sync_group if (has_bn and not use_running) else None
@@ -715,9 +759,14 @@ class _AffineNeuron(Function):
             sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
         # eval-mode BN has no batch coupling: dy = alpha * gx, applied while gx is written
         apply_scale = 1 if (has_bn and use_running) else 0
-        _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy, _ptr(g_vT),
-                  _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0), _ptr(sums),
-                  T, M, C, params, st)
+        if ctx.ckpt:
+            _hip.call("snn_lif_bwd_ckpt", g_out.data_ptr(), ldg, state.data_ptr(), y.data_ptr(), ldy, _ptr(g_vT),
+                      _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0),
+                      _ptr(sums), T, M, C, params, st)
+        else:
+            _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy,
+                      _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0),
+                      _ptr(g_i0), _ptr(sums), T, M, C, params, st)
         dy = dgamma = dbias = None
         if need_sums:
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)

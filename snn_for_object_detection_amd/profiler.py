@@ -59,6 +59,14 @@ def work_of(name: str, a):
         elems = float(T) * M * C
         tensors = 2 + (1 if a[3] is not None else 0) + (1 if a[14] is not None else 0)
         return f"k_affine_neuron_bwd<{neuron}>", 16.0 * elems, 4.0 * elems * tensors
+    if name == "snn_lif_fwd_ckpt":  # y, out (+ shortcut), checkpoints = 2/K of a tensor
+        T, M, C = a[13], a[14], a[15]
+        elems = float(T) * M * C
+        return "k_affine_neuron_fwd<1,ckpt>", 12.0 * elems, 4.0 * elems * (2.5 + (1 if a[8] is not None else 0))
+    if name == "snn_lif_bwd_ckpt":  # g_out, y, gx, checkpoints
+        T, M, C = a[14], a[15], a[16]
+        elems = float(T) * M * C
+        return "k_lif_bwd_ckpt", 28.0 * elems, 4.0 * elems * 3.5
     if name == "snn_bn_stats":
         T, M, C = a[2], a[3], a[4]
         return "k_bn_stats", 3.0 * T * M * C, 4.0 * T * M * C
