@@ -945,10 +945,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
                                                  xbytes > 0x7fffffffLL ? 0x7fffffff : (xbytes < 0 ? 0 : (int)xbytes), 0x00020000);
     }
 
-    // ---- loader geometry: thread -> (pixel quad = tid % NQ, channel group = tid / NQ + GPP * pass): the 16 lanes of
-    // one LDS store group write whole 16-dword runs of a column - conflict-free.  (Consecutive lanes on consecutive
-    // channel groups put all 16 lanes on 2 bank pairs: measured 75 % of all LDS cycles were bank conflicts.)
-    const int quad = tid % NQ, grp0 = tid / NQ;
+    // ---- loader geometry: 4 consecutive lanes take 4 consecutive channel groups (64 contiguous bytes) of one pixel
+    // quad, the next 4 lanes the next quad: thread -> (group = tid % 4 + 4 * (tid / (4 NQ)) + GPP * pass, quad =
+    // (tid / 4) % NQ).  The vector memory path then sees 64-byte accesses (with one lane per pixel it handled 64
+    // separate 16-byte accesses per load instruction: TA busy 75 % of the kernel on the 32-channel layers), and the
+    // LDS stores of a half-wave still fall on 32 distinct bank pairs: (16 g + 2 quad + const) mod 64, g < 4, quad < 8.
+    // (ALL lanes on consecutive channel groups collide - 75 % of the LDS cycles were bank conflicts.)
+    const int quad = (tid >> 2) % NQ, grp0 = (tid & 3) + 4 * (tid / (4 * NQ));
     int d_off[DQ];       // byte offset of (pixel quad*4, channel group) inside a stage; -1: channels past Cout
     int x_tapoff[XQ];    // byte offset of (tap, ci) relative to a pixel origin
     int x_kh[XQ], x_kw[XQ], x_cq[XQ], d_cq[DQ];
@@ -1766,8 +1769,9 @@ static WgradTile wgrad_tile(int Cout, int Ktot, bool split) {
     for (const WgradTile& c : cand) {
         double padded = (double)(snn_ceil_div(Cout, c.bm) * c.bm) * (double)(snn_ceil_div(Ktot, c.bn) * c.bn);
         double eff = (double)Cout * Ktot / padded;
-        // with the bf16x3 MFMAs (5x cheaper) the per-stage overhead dominates: favour the large tiles (measured)
-        if (split && c.id <= 1) eff *= 1.4;
+        // with the bf16x3 MFMAs (5x cheaper) the per-stage overhead dominates: favour the 128 x 128 tile (measured;
+        // 64 -> 64 3x3 is faster on nine 64 x 64 tiles than on three 64 x 256 ones since the loader is coalesced)
+        if (split && c.id == 0) eff *= 1.4;
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
             best = c;
@@ -1786,9 +1790,16 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
     // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time);
     // residency of the bf16x3 (pipelined) variants by registers / LDS
-    static const int split_resident[6] = {3, 2, 2, 3, 3, 3};  // measured optimum (sweep over 2..6) per tile variant
+    // (tools/wgrad_sweep.py over the layer shapes of TinyYolo GEN1, residency 2..4 per variant)
+    static const int split_resident[6] = {3, 2, 2, 3, 3, 3};
     int resident = split_mode ? split_resident[t.id] : t.blocks_per_cu;
-    if (split_mode && t.id == 0 && Cout <= t.bm) resident = 2;  // one row of tiles: fewer, longer splits win
+    if (split_mode && t.id == 4) resident = KH * KW > 1 ? 4 : 2;
+    if (split_mode && t.id == 0) {
+        // three blocks per CU only while a split keeps >= 24 stages of 32 pixels; shorter splits are all prologue
+        const int64_t s3 = (3 * (int64_t)SNN_NUM_CU) / tiles;
+        const int64_t s3r = s3 >= 32 ? s3 / 8 * 8 : (s3 < 1 ? 1 : s3);
+        if (M / s3r < 24 * WB_K) resident = 2;
+    }
     if (const char* force = getenv("SNN_WGRAD_RESIDENT")) resident = atoi(force) > 0 ? atoi(force) : resident;  // tuning aid
     int64_t s = ((int64_t)resident * SNN_NUM_CU) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
