@@ -226,7 +226,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
-        cpu = cpu_baseline(sample_T=8, sample_B=2, H=H, W=W, num_classes=args.classes, threads=threads)
+        # bounded sample of the same workload: the full batch of 5, half the timesteps (about 10 s of CPU work, 26 GiB)
+        cpu = cpu_baseline(sample_T=min(T, 16), sample_B=B, H=H, W=W, num_classes=args.classes, threads=threads)
 
     if world > 1:
         dist.barrier()
