@@ -78,7 +78,7 @@ def _stream() -> int:
 # data-gradient chain (fills the CUs that small feature maps leave idle).  ``wgrad_stream_sync()`` joins the
 # side stream; trainer.FlatTrainer.step() calls it before the all-reduce / optimiser read the gradients.
 _SIDE_STREAMS = {}
-USE_WGRAD_STREAM = True
+USE_WGRAD_STREAM = not os.environ.get("SNN_NO_WGRAD_STREAM")   # tuning aid: everything on one stream
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
