@@ -1676,6 +1676,133 @@ extern "C" int snn_set_forward_precision(int mode) {
 }
 extern "C" int snn_get_forward_precision(void) { return g_forward_split; }
 
+// ------------------------------------------------------------------------------------------ first layer
+// The convolution over the 2-channel event frames (Cin = 2, 3x3: K = 18) does not belong on the matrix pipe
+// (SURVEY 8d): its cost is writing y (forward) / reading dy (weight gradient).  Direct kernels: a thread owns 4
+// output channels with their 4 x 18 weights (forward) or 4 x 18 gradient accumulators (backward) in registers and
+// walks output pixels; the 16 threads of a pixel read the same 9 input positions (one broadcast access each).
+// (Skipping the taps whose input is 0 - event frames are sparse - was measured and does not pay: the 18 divergent
+// branches per pixel cost more issue slots than the 72 fmaf they save.)
+// Arithmetic: fp32 fmaf chain over (kh, kw, ci) in order, for every precision mode.
+namespace {
+struct FirstGeom {
+    int64_t ldx, ldy;
+    int rows;  // N * Ho output rows
+    int H, W, Ho, Wo, Cout, stride, pad;
+};
+
+// One block walks output ROWS (block-uniform row index: the image / row split and the vertical bounds are scalar
+// work), its PP pixel lanes walk the row; per pixel all nine input positions are loaded before any is tested.
+template <int CIN, int KS, bool WGRAD>
+__global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ dy, float* __restrict__ out,
+                                                         FirstGeom g) {
+    static_assert(CIN == 2, "float2 input pixels");
+    constexpr int KT = KS * KS * CIN;
+    __shared__ float red[WGRAD ? kThreads : 1][KT + 1];
+    extern __shared__ __attribute__((aligned(16))) float2 srow[];   // [KS][W + 2 pad] input rows of the current output row
+    const int cgs = g.Cout / 4;                       // channel groups: a power of two <= 64
+    const int cg = threadIdx.x % cgs, pl = threadIdx.x / cgs, PP = kThreads / cgs;
+    float wr[4][KT];                                  // forward: weights; weight gradient: accumulators
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) wr[c][k] = WGRAD ? 0.f : w[(cg * 4 + c) * KT + k];
+    const int ldx = (int)g.ldx, ldy = (int)g.ldy;
+    for (int r = blockIdx.x; r < g.rows; r += gridDim.x) {
+        const int img = r / g.Ho, oy = r - img * g.Ho;
+        const int iy0 = oy * g.stride - g.pad;
+        const float* xrow[KS];
+        bool rowok[KS];
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+            const int iy = iy0 + kh;
+            rowok[kh] = (unsigned)iy < (unsigned)g.H;
+            xrow[kh] = x + ((int64_t)img * g.H + (rowok[kh] ? iy : 0)) * g.W * g.ldx;
+        }
+        // the KS input rows (with their zero padding) go through LDS: the 16 lanes of a pixel read the same nine
+        // positions, and same-address lanes of a global load are separate accesses for the texture addresser
+        const int LW = g.W + 2 * g.pad;
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+            for (int ixp = threadIdx.x; ixp < LW; ixp += kThreads) {
+                const int ix = ixp - g.pad;
+                const bool ok = rowok[kh] && (unsigned)ix < (unsigned)g.W;
+                const float2 t = *reinterpret_cast<const float2*>(xrow[kh] + (ok ? ix * ldx : 0));
+                srow[kh * LW + ixp] = ok ? t : make_float2(0.f, 0.f);
+            }
+        __syncthreads();
+        const float* dyrow = WGRAD ? dy + (int64_t)r * g.Wo * g.ldy + cg * 4 : nullptr;
+        float* yrow = WGRAD ? nullptr : out + (int64_t)r * g.Wo * g.ldy + cg * 4;
+        for (int ox = pl; ox < g.Wo; ox += PP) {
+            float2 taps[KS][KS];
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow[kh * LW + ox * g.stride + kw];
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (WGRAD) gv = *reinterpret_cast<const f32x4*>(dyrow + ox * ldy);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    const float2 v = taps[kh][kw];
+                    const int k0 = (kh * KS + kw) * CIN;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (WGRAD) {
+                            wr[c][k0] = fmaf(gv[c], v.x, wr[c][k0]);
+                            wr[c][k0 + 1] = fmaf(gv[c], v.y, wr[c][k0 + 1]);
+                        } else {
+                            acc[c] = fmaf(v.x, wr[c][k0], acc[c]);
+                            acc[c] = fmaf(v.y, wr[c][k0 + 1], acc[c]);
+                        }
+                    }
+                }
+            if (!WGRAD) {
+                f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4*>(yrow + ox * ldy) = o;
+            }
+        }
+    }
+    if (WGRAD) {
+        // block sum over the PP pixel lanes of every channel group, in lane order; out = workspace, one slab
+        // [Cout][KT] per block, summed in fixed order by k_wgrad_reduce
+        float* slab = out + (int64_t)blockIdx.x * g.Cout * KT;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) red[threadIdx.x][k] = wr[c][k];
+            __syncthreads();
+            for (int e = threadIdx.x; e < cgs * KT; e += kThreads) {
+                const int gq = e / KT, k = e - gq * KT;
+                float sum = 0.f;
+                for (int q = 0; q < PP; ++q) sum += red[q * cgs + gq][k];
+                slab[(gq * 4 + c) * KT + k] = sum;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+// the shapes the two kernels above take: the caller checks alignment of its buffers on top
+static bool first_layer_shape(int Cin, int Cout, int KH, int KW) {
+    static const bool off = getenv("SNN_CONV_NO_FIRST") != nullptr;  // tuning / bisecting aid
+    if (off || Cin != 2 || KH != 3 || KW != 3 || Cout % 4 != 0 || Cout > 256) return false;
+    const int cgs = Cout / 4;
+    return (cgs & (cgs - 1)) == 0;
+}
+
+static int first_layer_blocks(int64_t rows) {  // grid of the row-walking kernels = slabs of the weight gradient
+    int64_t b = rows < 4 * SNN_NUM_CU ? rows : 4 * SNN_NUM_CU;
+    return b < 1 ? 1 : (int)b;
+}
+}  // namespace
+
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                               const float* addend, int64_t ld_addend, void* stream) {
@@ -1695,6 +1822,16 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
+    if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 && aligned16(y) &&
+        (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 2040 &&
+        (Wo - 1) * stride + 3 <= W + 2 * pad) {
+        FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
+        const int blocks = fg.rows < 8 * SNN_NUM_CU ? fg.rows : 8 * SNN_NUM_CU;
+        hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
+                           (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
+        SNN_CHECK_LAUNCH("snn_conv2d_fwd");
+        return 0;
+    }
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
         const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, g_forward_split, addend, ld_addend,
                                              nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
@@ -1785,6 +1922,7 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
     const int64_t M = N * Ho * (int64_t)Wo;
     const int64_t Ktot = (int64_t)KH * KW * Cin;
+    if (first_layer_shape(Cin, Cout, KH, KW)) return first_layer_blocks(N * Ho);  // one slab per block
     const bool split_mode = g_backward_split && Cin % 4 == 0 && Cout % 4 == 0;
     const WgradTile t = wgrad_tile(Cout, (int)Ktot, split_mode);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
@@ -1812,6 +1950,20 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     return (int)s;
 }
 
+// dw (+)= sum over the splitk workspace slabs, fixed order
+static int wgrad_reduce_slabs(const float* workspace, float* dw, int64_t n, int splitk, int accumulate, hipStream_t st) {
+#define SNN_REDUCE_LAUNCH(KG_)                                                                                  \
+    hipLaunchKernelGGL((k_wgrad_reduce<KG_>), dim3((unsigned)snn_ceil_div(n, kThreads / KG_)), dim3(kThreads), 0, \
+                       st, workspace, dw, n, splitk, accumulate)
+    if (splitk <= 8) SNN_REDUCE_LAUNCH(1);
+    else if (splitk <= 64) SNN_REDUCE_LAUNCH(4);
+    else if (splitk <= 256) SNN_REDUCE_LAUNCH(16);
+    else SNN_REDUCE_LAUNCH(64);
+#undef SNN_REDUCE_LAUNCH
+    SNN_CHECK_LAUNCH("snn_conv2d_wgrad_reduce");
+    return 0;
+}
+
 extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                                 int accumulate, float* workspace, int splitk, void* stream) {
@@ -1826,6 +1978,15 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
+    if (first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
+        (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 2040 &&
+        (Wo - 1) * stride + 3 <= W + 2 * pad) {
+        FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
+        hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
+                           (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
+        SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
+        return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
+    }
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);
     const WgradTile t = wgrad_tile(Cout, g.Ktot, g_backward_split && Cin % 4 == 0 && Cout % 4 == 0);
@@ -1869,15 +2030,5 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     }
 #undef SNN_WGRAD_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
-    const int64_t n = (int64_t)Cout * g.Ktot;
-#define SNN_REDUCE_LAUNCH(KG_)                                                                                  \
-    hipLaunchKernelGGL((k_wgrad_reduce<KG_>), dim3((unsigned)snn_ceil_div(n, kThreads / KG_)), dim3(kThreads), 0, \
-                       st, workspace, dw, n, splitk, accumulate)
-    if (splitk <= 8) SNN_REDUCE_LAUNCH(1);
-    else if (splitk <= 64) SNN_REDUCE_LAUNCH(4);
-    else if (splitk <= 256) SNN_REDUCE_LAUNCH(16);
-    else SNN_REDUCE_LAUNCH(64);
-#undef SNN_REDUCE_LAUNCH
-    SNN_CHECK_LAUNCH("snn_conv2d_wgrad_reduce");
-    return 0;
+    return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, st);
 }

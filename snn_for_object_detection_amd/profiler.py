@@ -26,6 +26,9 @@ def _conv_label(name: str, a) -> str:
     dgrad = name == "snn_conv2d_dgrad"
     cin, cout = a[8], a[11]
     oc, ic = (cin, cout) if dgrad else (cout, cin)
+    if not dgrad and cin == 2 and a[12] == 3 and a[13] == 3 and cout % 4 == 0 and (cout // 4) & (cout // 4 - 1) == 0 \
+            and cout <= 256 and a[16] is None:
+        return "k_conv_first<2, 3, false>"  # direct row kernel of the event-frame layer
     if a[12] == 3 and a[13] == 3 and a[14] == 1 and a[15] == 1 and oc <= 32 and oc % 4 == 0 and ic % 32 == 0:
         return f"k_conv_direct3<32, 4, 1, {'true' if dgrad else 'false'}>"  # halo-resident 3x3 kernel
     if oc <= 32:

@@ -24,7 +24,9 @@ def HF(hip_lib):
 
 CONV_CASES = [
     # T, B, Cin, H, W, Cout, k, s
-    (2, 2, 2, 17, 23, 64, 3, 2),      # first layer: Cin=2 scalar gather, K=18
+    (2, 2, 2, 17, 23, 64, 3, 2),      # first layer (direct row kernels k_conv_first): Cin=2, K=18, stride 2
+    (1, 3, 2, 9, 11, 16, 3, 1),       # the same kernels at stride 1, 16 channels (64 pixel lanes > row length)
+    (2, 1, 2, 10, 13, 36, 3, 2),      # Cin=2 with a channel count the row kernels do not take: generic scalar gather
     (2, 1, 32, 12, 19, 32, 3, 1),     # BN=32 tile
     (1, 2, 64, 9, 11, 128, 3, 2),     # stride 2, odd sizes, BN=128 tile
     (2, 1, 128, 8, 10, 64, 1, 1),     # 1x1

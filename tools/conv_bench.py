@@ -44,6 +44,8 @@ def main():
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
         x = torch.randn(N, H, W, Cin, device=dev)
+        if Cin == 2:  # the event-frame layer sees sparse binary input
+            x = (torch.rand(N, H, W, Cin, device=dev) < float(os.environ.get("EVENT_P", "0.05"))).float()
         w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
         wt = torch.empty(Cin, k, k, Cout, device=dev)
         y = torch.empty(N, Ho, Wo, Cout, device=dev)

@@ -23,6 +23,8 @@ def family(name: str) -> str:
     if base == "k_conv_gather":  # <BN, WM, WN, DGRAD, VEC, ...>: the first five arguments, as profiler.py labels them
         t = re.search(r"k_conv_gather<([^>]*)>", name)
         return f"k_conv_gather<{', '.join(a.strip() for a in t.group(1).split(',')[:5])}>" if t else base
+    if base == "k_conv_first":  # <CIN, KS, WGRAD>: the weight-gradient instance belongs to snn_conv2d_wgrad
+        return "k_conv_wgrad" if re.search(r"k_conv_first<[^>]*true>", name) else "k_conv_first<2, 3, false>"
     if base.startswith("k_conv_wgrad") or base == "k_wgrad_reduce":
         return "k_conv_wgrad"  # one snn_conv2d_wgrad call = one tile kernel (any variant) + its ordered reduce
     return base
