@@ -1823,7 +1823,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
     if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 && aligned16(y) &&
-        (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 2040 &&
+        (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
         FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
         const int blocks = fg.rows < 8 * SNN_NUM_CU ? fg.rows : 8 * SNN_NUM_CU;
@@ -1979,7 +1979,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
     if (first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
-        (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 2040 &&
+        (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
         FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
         hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
