@@ -370,6 +370,7 @@ constexpr int kWaves = kThreads / 64;
 struct BwdPlan {
     int vec, cvb, gy, gx, mode;  // mode 0: no sums, 1: ordered (shuffle + per-wave slabs), 2: LDS atomics
     size_t lds_bytes;
+    int64_t rpb;                 // pixel rows per block
 };
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -411,10 +412,17 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     if (cap < 1) cap = 1;
     const int64_t rpb = snn_ceil_div(rows, rows < cap ? rows : cap);
     pl.gx = (int)snn_ceil_div(rows, rpb);
+    pl.rpb = rpb;
     return pl;
 }
 
-template <int NEURON, int VEC, int MODE>
+// BUF (VEC = 4 only): the per-timestep operands are addressed through raw buffer resources - one per tensor and
+// timestep, lane offset -1 for lanes outside the tensor, so loads return zeros and stores are dropped by the hardware
+// range check.  The time loop is then straight-line code.  With per-pixel `if (ok)` branches the compiler's waitcnt
+// pass could not tell the prefetched loads of step t-1 from the ones step t needs and waited for ALL of them before
+// every pixel (vmcnt(0)): the prefetch bought nothing and the kernel ran at 3.9 TB/s with the texture addresser 16 %
+// busy.  Host-checked: one timestep of every tensor is < 2 GiB.
+template <int NEURON, int VEC, int MODE, bool BUF>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
@@ -461,14 +469,46 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             }
         }
         // Two register sets: the loads of timestep t-1 are in flight while timestep t is processed.
-        auto fetch = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
+        int og[NP], os[NP], oy[NP];  // BUF: byte offsets inside one timestep of g_out / (state, gx) / y; -1 = no pixel
+        if constexpr (BUF) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                if (ok[q]) {
-                    const int64_t row = (int64_t)t * M + mq[q];
-                    go[q] = Vec<VEC>::load(g_out + row * ldg + c);
-                    if (kNeedsState) st[q] = Vec<VEC>::load(state + row * C + c);
-                    if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
+                og[q] = ok[q] ? (int)((mq[q] * ldg + c) * 4) : -1;
+                os[q] = ok[q] ? (int)((mq[q] * C + c) * 4) : -1;
+                oy[q] = ok[q] ? (int)((mq[q] * ldy + c) * 4) : -1;
+            }
+        }
+        auto slab = [&](const float* base, int t, int64_t ld) {  // buffer resource of timestep t of a [T][M][ld] tensor
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)t * M * ld), 0, (int)(M * ld * 4),
+                                                     0x00020000);
+        };
+        auto fetch = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
+            if constexpr (BUF) {
+                const __amdgpu_buffer_rsrc_t rg = slab(g_out, t, ldg);
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    go[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rg, og[q], 0, 0));
+                if (kNeedsState) {
+                    const __amdgpu_buffer_rsrc_t rs = slab(state, t, C);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        st[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, os[q], 0, 0));
+                }
+                if (MODE != 0 || kNeedsX) {
+                    const __amdgpu_buffer_rsrc_t ry = slab(y, t, ldy);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        yv[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ry, oy[q], 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (ok[q]) {
+                        const int64_t row = (int64_t)t * M + mq[q];
+                        go[q] = Vec<VEC>::load(g_out + row * ldg + c);
+                        if (kNeedsState) st[q] = Vec<VEC>::load(state + row * C + c);
+                        if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
+                    }
                 }
             }
         };
@@ -490,9 +530,11 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         lane<VEC>(xa[q], j) = alpha ? lane<VEC>(yv[q], j) * lane<VEC>(a1, j) + lane<VEC>(b1, j)
                                                     : lane<VEC>(yv[q], j);
             }
+            [[maybe_unused]] __amdgpu_buffer_rsrc_t rgx;
+            if constexpr (BUF) rgx = slab(gx, t, C);
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                if (!ok[q]) continue;
+                if (!BUF && !ok[q]) continue;  // BUF: lanes without a pixel compute on zeros, their store is dropped
                 const int64_t row = (int64_t)t * M + mq[q];
                 V g;
 #pragma unroll
@@ -557,7 +599,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
                 }
-                Vec<VEC>::store(gx + row * C + c, g);
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rgx, 0, 0, 0)), g), rgx, os[q],
+                        0, 0);
+                else
+                    Vec<VEC>::store(gx + row * C + c, g);
             }
             if (MODE == 1) {
                 // lanes l and l ^ stride (stride a multiple of cvb) hold the same channels
@@ -1150,10 +1197,15 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
     return (size_t)pl.gx * T * C * 2;
 }
 
-#define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                                                                      \
-    hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_>), grid, dim3(kThreads), pl.lds_bytes,           \
+#define SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, BUF_)                                                               \
+    hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_, BUF_>), grid, dim3(kThreads), pl.lds_bytes,     \
                        (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, \
                        g_v0, g_i0, sums, T, M, C, pl.cvb, *p)
+#define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                           \
+    do {                                                              \
+        if (VEC_ == 4 && buf_ok) SNN_LAUNCH_BWD_(NEURON, 4, MODE_, true); \
+        else SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, false);             \
+    } while (0)
 #define SNN_DISPATCH_BWD(NEURON)                                  \
     do {                                                          \
         if (pl.vec == 4) {                                        \
@@ -1190,6 +1242,12 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
         SNN_REQUIRE(ok, "snn_affine_neuron_bwd: buffers must be 16-byte aligned when C%%4==0");
     }
     dim3 grid(pl.gx, pl.gy);
+    // buffer addressing (see k_affine_neuron_bwd): one timestep of every tensor must fit a 31-bit byte offset
+    static const bool no_buf = getenv("SNN_BWD_NO_BUF") != nullptr;  // tuning / bisecting aid
+    const int64_t ld_max = ldg > ldy ? (ldg > C ? ldg : C) : (ldy > C ? ldy : C);
+    // (blocks with a single pixel row keep the branchy kernel: three of its four pixel slots are empty, and empty
+    // slots cost nothing there while the straight-line kernel computes and issues them - measured 45 vs 58 us)
+    const bool buf_ok = !no_buf && M * ld_max * 4 < 0x7fffffffLL && pl.rpb >= 2;
     switch (neuron) {
         case SNN_NEURON_NONE: SNN_DISPATCH_BWD(SNN_NEURON_NONE); break;
         case SNN_NEURON_LIF: SNN_DISPATCH_BWD(SNN_NEURON_LIF); break;
