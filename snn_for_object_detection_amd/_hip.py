@@ -97,7 +97,7 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.snn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnn_hip.so ABI {lib.snn_abi_version()} != binding {ABI_VERSION}: rebuild")
-    # optional process-wide arithmetic overrides (defaults: forward bf16x6, backward bf16x3)
+    # optional process-wide arithmetic overrides (defaults: forward fp16x3, backward bf16x3)
     fwd = os.environ.get("SNN_FORWARD_PRECISION")
     if fwd:
         lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3, "fp16x3": 4}[fwd])
