@@ -1243,7 +1243,7 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     }
     dim3 grid(pl.gx, pl.gy);
     // buffer addressing (see k_affine_neuron_bwd): one timestep of every tensor must fit a 31-bit byte offset
-    static const bool no_buf = getenv("SNN_BWD_NO_BUF") != nullptr;  // tuning / bisecting aid
+    const bool no_buf = getenv("SNN_BWD_NO_BUF") != nullptr;  // tuning / bisecting aid (read per call: tests flip it)
     const int64_t ld_max = ldg > ldy ? (ldg > C ? ldg : C) : (ldy > C ? ldy : C);
     // (blocks with a single pixel row keep the branchy kernel: three of its four pixel slots are empty, and empty
     // slots cost nothing there while the straight-line kernel computes and issues them - measured 45 vs 58 us)

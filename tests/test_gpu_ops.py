@@ -185,6 +185,37 @@ def test_checkpointed_lif_is_bit_identical(HF, C, H, W, T, B, with_bn):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("C,H,W,T,B", [(64, 60, 76, 4, 5), (24, 96, 120, 3, 2), (256, 30, 38, 2, 3)])
+def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
+    """Layers with several pixel rows per block take the buffer-addressed, branch-free backward scan; SNN_BWD_NO_BUF
+    forces the pointer / per-pixel-branch kernel.  Same arithmetic in the same order: every gradient must agree bit
+    for bit where the BatchNorm sums are ordered (power-of-two group counts), to rounding where they use LDS atomics
+    (C = 24)."""
+    import os
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(C + H)
+    y = (2.5 * torch.randn(T, B, C, H, W) + 0.3).cuda().requires_grad_()
+    x = torch.randn(T, B, C, H, W).cuda().requires_grad_()
+    g = torch.randn(T, B, C, H, W).cuda()
+    results = []
+    for no_buf in (False, True):
+        if no_buf:
+            os.environ["SNN_BWD_NO_BUF"] = "1"
+        try:
+            bn = torch.nn.BatchNorm2d(C).cuda().train()
+            out, st = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn, addend=x)
+            results.append(torch.autograd.grad(out, (y, x, bn.weight, bn.bias), g))
+        finally:
+            os.environ.pop("SNN_BWD_NO_BUF", None)
+    ordered = (C // 4) & (C // 4 - 1) == 0
+    for a, b in zip(*results):
+        assert torch.isfinite(a).all()
+        if ordered:
+            assert torch.equal(a, b)
+        else:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
 def _oracle_norm_neuron(y, bn, cell, tanh=False, state=None):
     outs = []
     for t in range(y.shape[0]):
