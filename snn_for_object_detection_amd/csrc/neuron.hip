@@ -422,14 +422,13 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
 // pass could not tell the prefetched loads of step t-1 from the ones step t needs and waited for ALL of them before
 // every pixel (vmcnt(0)): the prefetch bought nothing and the kernel ran at 3.9 TB/s with the texture addresser 16 %
 // busy.  Host-checked: one timestep of every tensor is < 2 GiB.
-template <int NEURON, int VEC, int MODE, bool BUF>
+template <int NEURON, int VEC, int MODE, bool BUF, int NP>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
     const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
     float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p) {
     typedef typename Vec<VEC>::type V;
-    constexpr int NP = kBwdNP;
     constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
     constexpr bool kNeedsState = (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH || kNeedsX);
     extern __shared__ __attribute__((aligned(16))) float red[];  // MODE 1: [wave][T][cb][2]; MODE 2: [T][cb][2]
@@ -1197,14 +1196,15 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
     return (size_t)pl.gx * T * C * 2;
 }
 
-#define SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, BUF_)                                                               \
-    hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_, BUF_>), grid, dim3(kThreads), pl.lds_bytes,     \
+#define SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, BUF_, NP_)                                                          \
+    hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_, BUF_, NP_>), grid, dim3(kThreads), pl.lds_bytes, \
                        (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, \
                        g_v0, g_i0, sums, T, M, C, pl.cvb, *p)
-#define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                           \
-    do {                                                              \
-        if (VEC_ == 4 && buf_ok) SNN_LAUNCH_BWD_(NEURON, 4, MODE_, true); \
-        else SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, false);             \
+#define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                                             \
+    do {                                                                                \
+        if (VEC_ == 4 && buf_ok && pl.rpb == 1) SNN_LAUNCH_BWD_(NEURON, 4, MODE_, true, 1); \
+        else if (VEC_ == 4 && buf_ok) SNN_LAUNCH_BWD_(NEURON, 4, MODE_, true, kBwdNP);  \
+        else SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, false, kBwdNP);                       \
     } while (0)
 #define SNN_DISPATCH_BWD(NEURON)                                  \
     do {                                                          \
@@ -1245,9 +1245,9 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     // buffer addressing (see k_affine_neuron_bwd): one timestep of every tensor must fit a 31-bit byte offset
     const bool no_buf = getenv("SNN_BWD_NO_BUF") != nullptr;  // tuning / bisecting aid (read per call: tests flip it)
     const int64_t ld_max = ldg > ldy ? (ldg > C ? ldg : C) : (ldy > C ? ldy : C);
-    // (blocks with a single pixel row keep the branchy kernel: three of its four pixel slots are empty, and empty
-    // slots cost nothing there while the straight-line kernel computes and issues them - measured 45 vs 58 us)
-    const bool buf_ok = !no_buf && M * ld_max * 4 < 0x7fffffffLL && pl.rpb >= 2;
+    // (blocks with a single pixel row take the one-pixel-per-thread instance: the three empty pixel slots of the
+    // four-pixel one are computed and issued in straight-line code - measured 58 us against 45 for the branchy kernel)
+    const bool buf_ok = !no_buf && M * ld_max * 4 < 0x7fffffffLL;
     switch (neuron) {
         case SNN_NEURON_NONE: SNN_DISPATCH_BWD(SNN_NEURON_NONE); break;
         case SNN_NEURON_LIF: SNN_DISPATCH_BWD(SNN_NEURON_LIF); break;
