@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: event-frames/s (B x T) of one SODa / TinyYolo training step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config gen1|1mpx|deep12]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = the whole hot path on one batch of synthetic GEN1-shaped events (BASELINE.json configs[1]:
-SODa 3M / TinyYolo, 304x240, B=5, T=32 per GPU): layer-major forward over all T, detection loss on
-the last timestep, BPTT backward producing every parameter gradient, (N>1: one RCCL all-reduce of the
-flat gradient), fused Adamax update.  Inputs are resident in HBM before the timed region.
+One step = the whole hot path on one batch of synthetic events: layer-major forward over all T, loss on the
+last timestep, BPTT backward producing every parameter gradient, (N>1: one RCCL all-reduce of the flat
+gradient), fused Adamax update.  Inputs are resident in HBM before the timed region.
+
+Workloads (``--config``; per-GPU batch, weak scaling):
+  gen1   (default, the headline: BASELINE.json configs[1] / [2]) SODa 3M / TinyYolo, GEN1 304x240, B=5, T=32
+  1mpx   BASELINE.json configs[3]: TinyYolo, 1 Mpx 1280x720, 7 classes, B=8, T=32 (about 250 GiB of HBM)
+  deep12 BASELINE.json configs[4]: 12 x {Conv(64,3), Norm, LIF} on 304x240, T=128, B=2 per GPU (16 on 8 GPUs)
 
 Prints ONE JSON line (rank 0).  Beside the contract fields it carries
   "roofline":     the dominant kernel's achieved rate (HIP events on the launch stream, algorithmic
                   FLOPs of SURVEY 8(d)) against the MI355X peak,
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference, time-outer loop) timed
-                  on this host on a bounded sample of the same workload (rank 0, N=1 only).
+                  on this host on a bounded sample of the same workload (rank 0, N=1 only),
+  "dist":         the torch.distributed backend that carried the gradient all-reduce and the ranks it saw.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,13 +35,25 @@ sys.path.insert(0, ROOT)
 
 GEN1_H, GEN1_W = 240, 304
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense bf16 MFMA
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0
+
+# name -> (H, W, classes, per-GPU batch, T, event density, CPU-baseline sample (B, T))
+CONFIGS = {
+    "gen1": dict(H=GEN1_H, W=GEN1_W, classes=2, batch=5, T=32, p=0.05, cpu_sample=(5, 16),
+                 label="SODa/TinyYolo (4.23M params) GEN1 304x240"),
+    "1mpx": dict(H=720, W=1280, classes=7, batch=8, T=32, p=0.05, cpu_sample=(1, 4),
+                 label="SODa/TinyYolo (4.26M params) 1Mpx 1280x720, 7 classes"),
+    "deep12": dict(H=GEN1_H, W=GEN1_W, classes=0, batch=2, T=128, p=0.3, cpu_sample=(1, 8),
+                   label="deep backbone 12 x {Conv(64,3), Norm, LIF} on GEN1 304x240"),
+}
+# significant bits of one product of each convolution arithmetic (include/snn_hip.h, SNN_PREC_*)
+PRODUCT_BITS = {"fp32": 24, "fp16x3": 22, "bf16x6": 24, "bf16x3": 16}
 
 
 def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
-    """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3) or 6 (bf16x6) dense
-    bf16 MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
+    """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3 / fp16x3) or 6 (bf16x6)
+    dense 16-bit MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
     backward = (kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
                 or kernel.endswith(", true>"))  # k_conv_direct3<BN, WM, WN, DGRAD>
     prec = bwd_prec if backward else fwd_prec
@@ -48,9 +66,9 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA"
 
 
-def synthetic_batch(T, B, H, W, num_classes, device, seed):
+def synthetic_batch(T, B, H, W, num_classes, device, seed, p=0.05):
     g = torch.Generator().manual_seed(seed)
-    X = (torch.rand(T, B, 2, H, W, generator=g) < 0.05).float()
+    X = (torch.rand(T, B, 2, H, W, generator=g) < p).float()
     labels = torch.full((B, 2, 5), -1.0)
     for b in range(B):
         for k in range(2):
@@ -59,27 +77,86 @@ def synthetic_batch(T, B, H, W, num_classes, device, seed):
                 lo, hi = xy.min(0).values, xy.max(0).values
                 if (hi - lo).prod() > 0.01:
                     break
-            labels[b, k, 0] = float(torch.randint(0, num_classes, (1,), generator=g))
+            labels[b, k, 0] = float(torch.randint(0, max(num_classes, 1), (1,), generator=g))
             labels[b, k, 1:3], labels[b, k, 3:5] = lo, hi
     return X.to(device), labels.to(device)
 
 
-def cpu_baseline(sample_T, sample_B, H, W, num_classes, threads):
+def deep12_cfg():
+    from snn_for_object_detection_amd import Conv, LIF, Norm
+    cfg = []
+    for _ in range(12):
+        cfg += [Conv(64, 3), Norm(), LIF()]
+    return cfg
+
+
+def deep12_probe(B, H, W, device):
+    """Read-out of the backbone at the last timestep: a fixed random projection (the gradient then flows back through
+    all T steps of all 12 layers)."""
+    return torch.randn(B, 64, H, W, generator=torch.Generator().manual_seed(3)).to(device)
+
+
+def csrc_fingerprint() -> str:
+    """sha256 over the kernel sources: ties a PMC traffic file to the kernels it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "snn_for_object_detection_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(config: str, kernel: str):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this workload
+    (tools/pmc_traffic.py; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  bench.py cannot run the profiler
+    on itself, so the number comes from profiles/ - and only while that file was measured on the CURRENT kernel
+    sources; otherwise the field is null and the provenance says why."""
+    name = f"r02_pmc_traffic_{config}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, {"file": None, "note": "no PMC traffic file for this workload under profiles/"}
+    data = json.load(open(path))
+    meta = data.get("_meta", {})
+    now = csrc_fingerprint()
+    src = {"file": f"profiles/{name}", "file_sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16],
+           "measured_on_csrc": str(meta.get("csrc_sha256", "?"))[:16], "current_csrc": now[:16]}
+    if meta.get("csrc_sha256") != now:
+        src["note"] = "stale: kernel sources changed since the PMC passes; traffic nulled"
+        return None, src
+    return data.get(kernel, {}).get("hbm_bytes_per_launch"), src
+
+
+def cpu_baseline(config, H, W, num_classes, threads, p):
     """Time the oracle (port of the reference path) on the host cores: 1 warm-up + 2 timed steps."""
-    from oracle.net import SODaRef
+    from oracle.net import BlockRef, SODaRef
     import snn_for_object_detection_amd as S
+    sample_B, sample_T = CONFIGS[config]["cpu_sample"]
     torch.set_num_threads(threads)
     torch.manual_seed(2)
-    desc = S.TinyYolo(num_classes=num_classes, time_window=0)
-    model = SODaRef(desc, num_classes, time_window=0)
-    model.load_state_dict(desc.state_dict())
-    model.train()
-    X, labels = synthetic_batch(sample_T, sample_B, H, W, num_classes, "cpu", seed=0)
+    X, labels = synthetic_batch(sample_T, sample_B, H, W, num_classes, "cpu", seed=0, p=p)
+    if config == "deep12":
+        model = BlockRef(2, deep12_cfg()).train()
+        probe = deep12_probe(sample_B, H, W, "cpu")
+
+        def run():
+            state, out = None, None
+            for t in range(sample_T):
+                out, state = model(X[t], state)
+            return (out * probe).mean()
+    else:
+        desc = S.TinyYolo(num_classes=num_classes, time_window=0)
+        model = SODaRef(desc, num_classes, time_window=0)
+        model.load_state_dict(desc.state_dict())
+        model.train()
+
+        def run():
+            return model.training_step((X, labels))
     times = []
     for it in range(3):
         model.zero_grad(set_to_none=True)
         t0 = time.perf_counter()
-        loss = model.training_step((X, labels))
+        loss = run()
         loss.backward()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
@@ -89,20 +166,22 @@ def cpu_baseline(sample_T, sample_B, H, W, num_classes, threads):
         "cores": threads,
         "kind": "port",
         "sample": f"oracle (pure-PyTorch fp32 restatement, time-outer loop; norse not installed) fwd+bwd on "
-                  f"TinyYolo GEN1 {W}x{H} B={sample_B} T={sample_T}, best of 2 after 1 warm-up, {best:.2f} s/step",
+                  f"{CONFIGS[config]['label']} B={sample_B} T={sample_T}, best of 2 after 1 warm-up, {best:.2f} s/step",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=5, help="samples per GPU")
-    ap.add_argument("--timesteps", type=int, default=32)
-    ap.add_argument("--height", type=int, default=GEN1_H)
-    ap.add_argument("--width", type=int, default=GEN1_W)
-    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="gen1",
+                    help="workload: gen1 = BASELINE configs[1]/[2] (headline), 1mpx = configs[3], deep12 = configs[4]")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the config's)")
+    ap.add_argument("--timesteps", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--classes", type=int, default=None)
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
     ap.add_argument("--forward-precision", choices=("fp16x3", "bf16x6", "fp32"), default="fp16x3",
@@ -114,6 +193,14 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    T = args.timesteps or cfg["T"]
+    B = args.batch or cfg["batch"]
+    H, W = args.height or cfg["H"], args.width or cfg["W"]
+    classes = args.classes if args.classes is not None else cfg["classes"]
+    big = args.config != "gen1"
+    steps = args.steps if args.steps is not None else (6 if big else 20)
+    warmup = args.warmup if args.warmup is not None else (2 if big else 5)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +211,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") over xGMI is the production transport; SNN_DIST_BACKEND=gloo exists only to rehearse the
@@ -133,6 +221,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        backend = dist.get_backend()
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -144,24 +233,41 @@ def main():
     S.functional.set_forward_precision(args.forward_precision)
     S.functional.set_backward_precision(args.backward_precision)
 
-    T, B, H, W = args.timesteps, args.batch, args.height, args.width
     torch.manual_seed(2)  # same reference init on every rank
-    model = S.TinyYolo(num_classes=args.classes, time_window=0).to(device).train()
-    trainer = FlatTrainer(model, lr=model.hparams.learning_rate)
+    X, labels = synthetic_batch(T, B, H, W, classes, device, seed=rank, p=cfg["p"])  # a different shard per rank
+    if args.config == "deep12":
+        model = S.BlockGen(2, deep12_cfg())
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        model = model.to(device).train()
+        probe = deep12_probe(B, H, W, device)
+
+        def loss_fn():
+            out, _ = model(X)
+            return (out[-1] * probe).mean()
+        lr = 1e-3
+    else:
+        model = S.TinyYolo(num_classes=classes, time_window=0).to(device).train()
+
+        def loss_fn():
+            return model.training_step((X, labels))
+        lr = model.hparams.learning_rate
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    trainer = FlatTrainer(model, lr=lr)
     broadcast_parameters(trainer)
     if args.sync_bn and world > 1:
         from snn_for_object_detection_amd.trainer import convert_sync_batchnorm
         convert_sync_batchnorm(model)
-    X, labels = synthetic_batch(T, B, H, W, args.classes, device, seed=rank)  # a different shard per rank
 
     def step():
         trainer.zero_grad()
-        loss = model.training_step((X, labels))
+        loss = loss_fn()
         loss.backward()
         trainer.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
 
     def fence():
@@ -172,7 +278,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -180,8 +286,9 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    frames_per_s = world * B * T * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / steps
+    frames_per_s = world * B * T * steps / elapsed
+    peak_gib = torch.cuda.max_memory_allocated() / 2**30
 
     roofline = None
     if not args.no_roofline:
@@ -190,32 +297,29 @@ def main():
         from snn_for_object_detection_amd import functional as HF
         prof = KernelProfiler() if rank == 0 else None
         _hip.PROFILER = prof
+        side_stream_was = HF.USE_WGRAD_STREAM
         HF.USE_WGRAD_STREAM = False
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        HF.USE_WGRAD_STREAM = True
+        HF.USE_WGRAD_STREAM = side_stream_was
         _hip.PROFILER = None
     if rank == 0 and not args.no_roofline:
         table = prof.summary()
         total_ms = sum(r["ms"] for r in table.values())
         name, row = max(table.items(), key=lambda kv: kv[1]["ms"])
-        # HBM bytes per launch of that kernel: rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 per the
-        # gfx950 correction, + WRITE_SIZE; tools/pmc_traffic.py), committed under profiles/ - bench.py cannot
-        # run the profiler on itself, so the field is null when no such file is present
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and (T, B, H, W) == (32, 5, GEN1_H, GEN1_W):
-            traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+        default_shape = (T, B, H, W, classes) == (cfg["T"], cfg["batch"], cfg["H"], cfg["W"], cfg["classes"])
+        traffic, traffic_src = pmc_traffic(args.config, name) if default_shape else (None, {"note": "non-default shape"})
         peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
-            "unit": "TFLOP/s", "frac": row["tflops"] / peak, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": row["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
             "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
             "avg_launch_us": row["avg_us"], "launches_per_step": row["calls"] // 2,
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],
             "all_kernels_ms_per_step": total_ms / 2,
+            "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream off",
         }
         if args.kernel_table:
             for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
@@ -226,28 +330,36 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
-        # bounded sample of the same workload: the full batch of 5, half the timesteps (about 10 s of CPU work, 26 GiB)
-        cpu = cpu_baseline(sample_T=min(T, 16), sample_B=B, H=H, W=W, num_classes=args.classes, threads=threads)
+        cpu = cpu_baseline(args.config, H, W, classes, threads, cfg["p"])  # bounded sample: about 10-30 s of CPU work
 
     if world > 1:
         dist.barrier()
     if rank == 0:
+        exact = args.forward_precision == "fp32" and args.backward_precision == "fp32"
         out = {
-            "metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd",
+            "metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd" if args.config == "gen1"
+                      else f"event-frames/sec (BxT) {cfg['label']} fwd+bwd",
             "value": frames_per_s,
             "unit": "event-frames/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # fp32 tensors and fp32 accumulation in every mode; "f32" alone only when the products are exact fp32 too
+            "dtype": "f32" if exact else "f32 (16-bit split products)",
+            "arithmetic_bits": {"storage": 32, "accumulate": 32,
+                                "forward_product": PRODUCT_BITS[args.forward_precision],
+                                "backward_product": PRODUCT_BITS[args.backward_precision]},
             "data": "synthetic",
             "config": {
-                "workload": f"SODa/TinyYolo (4.23M params) GEN1 {W}x{H}, B={B}/GPU T={T}, p(event)=0.05, 2 boxes/sample, "
-                            "fwd + loss(last step) + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
+                "workload": f"{cfg['label']}, B={B}/GPU T={T}, p(event)={cfg['p']}, "
+                            + ("2 boxes/sample, fwd + loss(last step)" if args.config != "deep12"
+                               else "fwd + read-out loss(last step)")
+                            + " + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
+                "name": args.config, "trainable_params": n_params,
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
                 "sync_batchnorm": bool(args.sync_bn and world > 1),
                 "arithmetic": "fp32 storage and accumulation; forward conv "
@@ -260,7 +372,10 @@ def main():
                               + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, rel 1e-5)"
                                  if args.backward_precision == "bf16x3" else "exact fp32 MFMA"),
                 "loss": float(loss.item()),
+                "peak_hbm_gib": peak_gib,
             },
+            "dist": {"backend": backend, "world_size": world,
+                     "gradient_exchange": "one SUM all-reduce of the flat fp32 gradient per step" if world > 1 else None},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

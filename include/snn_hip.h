@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 4
+#define SNN_ABI_VERSION 5
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -44,6 +44,26 @@ enum {
     SNN_NEURON_SLI = 4,    /* saturable leaky integrator, sli.py:110-126          */
     SNN_NEURON_SYNAPSE = 5 /* mediator-concentration synapse, synapse.py:73-103   */
 };
+
+/* Arithmetic of a convolution call (the `precision` argument of snn_conv2d_*).  Tensors in HBM and the accumulators
+ * are fp32 in every mode; the modes differ in how the PRODUCTS are formed on the matrix cores:
+ *   SNN_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain.               fwd, dgrad, wgrad
+ *   SNN_PREC_BF16X3 operands split into bf16 hi + lo, product = hi*hi + hi*lo + lo*hi on the bf16 MFMA: relative
+ *                   error ~2^-16 per product (measured 1e-5).  Default of the backward convolutions.   dgrad, wgrad
+ *   SNN_PREC_BF16X6 three-way bf16 split of both operands (h + m + l = all 24 significant bits) and the six leading
+ *                   products: fp32-grade (rel 5e-7 vs fp64) for any fp32 range.                                 fwd
+ *   SNN_PREC_FP16X3 both operands split into two fp16 pieces (11 + 11 significant bits) after exact power-of-two
+ *                   pre-scaling (weights x 2^8, activations x 2^4), products hh + hl + lh: relative error 2^-22
+ *                   (measured 5e-7 vs fp64, equal to the fp32 MFMA's) at half the matrix work of BF16X6.  Range
+ *                   contract: |x| < 4094 and |w| < 255 (beyond: inf/NaN in the output - visible, not silent);
+ *                   values below |x| = 0.008 / |w| = 5e-4 keep an ABSOLUTE accuracy of 4e-9 / 2e-10 instead of 22
+ *                   bits.  Default of the forward convolution (inputs are spikes / normalised activations).     fwd
+ * The mode is an argument of every call - the library keeps no process-wide arithmetic state. */
+enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4 };
+
+/* flags of snn_affine_neuron_bwd */
+enum { SNN_SCAN_WIDE_ADDRESSING = 1 /* use 64-bit pointer addressing even when one timestep of every tensor fits the
+                                       31-bit buffer offsets (the library switches by itself when it does not) */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
@@ -83,7 +103,7 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d(bias=False, padding=int(k/2), stride=s) of layer_gen.py:129-136
  * (forward) and its autograd (ATen conv backward) for all T*B frames at once.
- * Implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled.
+ * Implicit GEMM on the matrix cores, LDS-tiled; `precision` = SNN_PREC_* (above).
  *
  * fwd  : y[n,ho,wo,co]   = sum_{kh,kw,ci} x[n, ho*s-pad+kh, wo*s-pad+kw, ci] * w[co,kh,kw,ci]
  * dgrad: dx[n,hi,wi,ci]  = sum_{kh,kw,co} dy[n,(hi+pad-kh)/s,(wi+pad-kw)/s,co] * wt[ci,kh,kw,co]
@@ -95,39 +115,24 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
  *   in the epilogue (result = conv + addend); passing the destination itself accumulates in place.  This
  *   fuses the gradient sum of a tensor consumed by several branches (generator.py:181-187) into the dgrad.
  * wgrad accumulate != 0 : the result is added to dw instead of overwriting it. */
-/* Arithmetic of the BACKWARD convolutions (process-wide): 0 = exact fp32 MFMA; 1 (default) = "bf16 x 3":
- * operands split into bf16 hi + lo, product = hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation,
- * relative error ~2^-16 per product. */
-int snn_set_backward_precision(int mode);
-int snn_get_backward_precision(void);
-/* Arithmetic of the FORWARD convolution (storage and accumulation are fp32 in every mode):
- *   4 (default) = "fp16 x 3": both operands split into two fp16 pieces (11 + 11 significant bits) after exact
- *       power-of-two pre-scaling (weights x 2^8, activations x 2^4), products hh + hl + lh with fp32 accumulation:
- *       relative error 2^-22 (measured 5e-7 vs fp64, equal to the fp32 MFMA's) at half the matrix work of mode 3.
- *       Range contract: |x| < 4094 and |w| < 255 (beyond: inf/NaN in the output - visible, not silent); values
- *       below |x| = 0.008 / |w| = 5e-4 keep an ABSOLUTE accuracy of 4e-9 / 2e-10 instead of 22 bits.
- *   3 = "bf16 x 6": three-way bf16 split of both operands (h + m + l = all 24 significant bits) and the six leading
- *       products - fp32-grade for any fp32 range.
- *   0 = exact fp32 MFMA (fmaf chain). */
-int snn_set_forward_precision(int mode);
-int snn_get_forward_precision(void);
-
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                   int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, void* stream);
+                   int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, int precision,
+                   void* stream);
 /* dgrad takes TWO optional addends (dx = conv^T(dy) + addend + addend2): a tensor consumed by a convolution, a
  * residual shortcut and a Dense pass-through (the YOLO bottleneck inside a C2f block) gets its whole gradient in one
  * epilogue instead of two extra add passes. */
 int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend,
-                     const float* addend2, int64_t ld_addend2, void* stream);
+                     const float* addend2, int64_t ld_addend2, int precision, void* stream);
 int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, int accumulate,
-                     float* workspace, int splitk, void* stream);
-/* number of pixel splits snn_conv2d_wgrad wants for this shape (workspace = splitk*Cout*KH*KW*Cin floats) */
-int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+                     float* workspace, int splitk, int precision, void* stream);
+/* number of pixel splits snn_conv2d_wgrad wants for this shape and precision (workspace = splitk*Cout*KH*KW*Cin
+ * floats); host-only, callable without a device */
+int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int precision);
 
 /* ---------------------------------------------------------------- batch-norm statistics
  * Train-mode nn.BatchNorm2d (layer_gen.py:211-214) applied per TIMESTEP: for every (t,c)
@@ -187,13 +192,14 @@ int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
  * backward (`sums` scratch of snn_affine_neuron_bwd_sums_size() doubles, y must be given).
  * `state` is the forward's vdec buffer for LIF / SLI / SYNAPSE, out (tanh output) for LI_TANH, unused otherwise.
  * alpha/beta (may be NULL = identity): the forward's affine, needed to rebuild x[t] for SLI / SYNAPSE.
- * apply_scale != 0: gx is multiplied by alpha[t,c] before it is written (eval-mode BN: dy = alpha*gx). */
+ * apply_scale != 0: gx is multiplied by alpha[t,c] before it is written (eval-mode BN: dy = alpha*gx).
+ * flags: 0 or SNN_SCAN_WIDE_ADDRESSING. */
 size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C);
 int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state,
                           const float* y, int64_t ldy, const float* g_vT, const float* g_iT,
                           const float* alpha, const float* beta, int apply_scale,
                           float* gx, float* g_v0, float* g_i0, double* sums,
-                          int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+                          int T, int64_t M, int C, const snn_neuron_params* p, int flags, void* stream);
 
 /* Memory-saving LIF pair (same results, bit for bit, as the two calls above with neuron = SNN_NEURON_LIF).  Instead
  * of vd[t] for every step, the forward stores the state (v, i) BEFORE every K-th step, K = snn_lif_ckpt_interval():
@@ -280,7 +286,8 @@ int snn_detect_decode(const float* cls_prob, const float* offsets, const float* 
 /* Per-class greedy NMS (utils/box.py:82-99).  order[A]: anchor ids sorted by (class ascending, confidence descending);
  * seg[num_classes + 1]: members of class c are order[seg[c] .. seg[c+1]).  kept[seg[c] ..) receives the kept ids of
  * class c in keep order, nkept[c] their number; kept_flag[id] = 1 and kept_rank[id] = rank inside its class for kept
- * anchors (both arrays must be zeroed by the caller).  One block per class; suppress when IoU > iou_threshold. */
+ * anchors (both arrays must be zeroed by the caller).  One block per class; a candidate survives
+ * only while IoU <= iou_threshold against every kept box (so a NaN IoU suppresses, as utils/box.py:95-97 does). */
 int snn_nms_sorted(const float* boxes, const int* order, const int* seg, int num_classes, float iou_threshold,
                    int* kept, int* nkept, unsigned char* kept_flag, int* kept_rank, void* stream);
 

@@ -37,8 +37,12 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """``tuning=True`` (``--tuning``): compile the bisecting / tuning environment knobs in (``-DSNN_TUNING``) and write
+    ``libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment."""
     hipcc = _hipcc()
+    if tuning:
+        return _build_tuning(hipcc, verbose)
     headers = [os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
@@ -65,5 +69,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _build_tuning(hipcc: str, verbose: bool) -> str:
+    out = os.path.join(HERE, "libsnn_hip_tuning.so")
+    cmd = [hipcc, *FLAGS, "-DSNN_TUNING", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

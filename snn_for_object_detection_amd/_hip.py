@@ -10,12 +10,14 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # SNN_HIP_LIB: tuning aid (ablation builds)
+LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # SNN_HIP_LIB: tuning aid (ablation / -DSNN_TUNING builds)
 
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3 = 0, 1, 3, 4   # SNN_PREC_* of include/snn_hip.h
+SCAN_WIDE_ADDRESSING = 1
 
 
 class NeuronParams(Structure):
@@ -36,15 +38,12 @@ SIGNATURES = {
     "snn_weight_transpose_batched": (c_int, [_P, _P, _P, _I, _P]),
     "snn_detect_decode": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "snn_nms_sorted": (c_int, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
-    "snn_set_backward_precision": (c_int, [_I]),
-    "snn_get_backward_precision": (c_int, []),
-    "snn_set_forward_precision": (c_int, [_I]),
-    "snn_get_forward_precision": (c_int, []),
-    "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
     "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L,
+                                 _I, _P]),
+    "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P]),
-    "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
-    "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I]),
+    "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I]),
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
     "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_bn_stats_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),
@@ -61,7 +60,7 @@ SIGNATURES = {
                                  POINTER(NeuronParams), _P]),
     "snn_affine_neuron_bwd_sums_size": (c_size_t, [_I, _L, _I]),
     "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
-                                      POINTER(NeuronParams), _P]),
+                                      POINTER(NeuronParams), _I, _P]),
     "snn_bn_bwd_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
     "snn_copy_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
@@ -97,13 +96,6 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.snn_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnn_hip.so ABI {lib.snn_abi_version()} != binding {ABI_VERSION}: rebuild")
-    # optional process-wide arithmetic overrides (defaults: forward fp16x3, backward bf16x3)
-    fwd = os.environ.get("SNN_FORWARD_PRECISION")
-    if fwd:
-        lib.snn_set_forward_precision({"fp32": 0, "bf16x6": 3, "fp16x3": 4}[fwd])
-    bwd = os.environ.get("SNN_BACKWARD_PRECISION")
-    if bwd:
-        lib.snn_set_backward_precision({"fp32": 0, "bf16x3": 1}[bwd])
     _lib = lib
     return lib
 

@@ -1,5 +1,9 @@
-// Implicit-GEMM 2-D convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32),
-// LDS-tiled, channels-last, all T*B frames of a layer in one launch.
+// Implicit-GEMM 2-D convolution on the gfx950 matrix cores, LDS-tiled, channels-last, all T*B frames of a layer
+// in one launch.  Tensors are fp32 in HBM and accumulation is fp32; the PRODUCTS run on the 16-bit matrix pipe from
+// pieces of the fp32 operands (split on the way into LDS), selected per call by the `precision` argument
+// (include/snn_hip.h, SNN_PREC_*): fp16 x 3 (default forward: v_mfma_f32_32x32x16_f16, fp32-grade), bf16 x 6
+// (fp32-grade for any range), bf16 x 3 (default backward: v_mfma_f32_32x32x16_bf16, rel 1e-5), or the exact fp32
+// MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain).
 //
 // Replaces nn.Conv2d(bias=False, padding=int(k/2)) forward and ATen's conv backward
 // (reference layer_gen.py:129-136) for the layer-major schedule.
@@ -9,11 +13,11 @@
 //       m = output pixel (img, oy, ox); k = (tap, c); n = output channel
 //       FWD  : A = x [img][oy*s-pad+kh][ox*s-pad+kw][c],             Wk = w  [Cout][taps][Cin]
 //       DGRAD: A = dy[img][(oy+pad-kh)/s][(ox+pad-kw)/s][c] (exact), Wk = wt [Cin][taps][Cout]
-//     block tile 128 pixels x BN channels x 32 k, 4 waves, 3 blocks / CU; LDS images [row][32+4] fp32 read
-//     with ds_read_b128 (the +4 pad makes the four 16-lane groups conflict-free); branch-free global ->
-//     register prefetch of tile k+1 (clamped addresses + select) overlaps the MFMAs of tile k; the data
-//     gradient of a strided conv is split into stride x stride phase classes that only visit reachable taps;
-//     the epilogue can add a same-shaped tensor (fused gradient accumulation).
+//     block tile 128 pixels x BN channels x 32 k, 4 waves; LDS images of 16-bit pieces, [row][32+8] with an 80-byte
+//     pitch read with ds_read_b128 (fp32 mode: [row][32+4] floats); software-pipelined main loop (convert tile k+1
+//     in the MFMA shadow of tile k, loads of tile k+2 in flight); the data gradient of a strided conv is split
+//     into stride x stride phase classes that only visit reachable taps; the epilogue can add up to two
+//     same-shaped tensors (fused gradient accumulation).
 //
 //   weight-gradient:
 //       dw[co][kc] = sum_pix dy[pix][co] * xg[pix][kc],  kc = (tap, ci)
@@ -21,8 +25,8 @@
 //     pixel ranges sized to ONE resident wave of blocks, splits pinned to XCDs (L2 reuse of dy / x),
 //     workspace slabs reduced in fixed order by k_wgrad_reduce (bitwise reproducible).
 //
-// fp32 MFMA is an exact k-ordered fmaf chain (no reduced precision), which is what the 1e-4
-// parity target against the CPU reference needs.
+// The split modes keep the 1e-4 parity target against the CPU reference: see DESIGN.md section 3 for the measured
+// errors of each mode.
 #include <stdlib.h>
 #include "snn_common.h"
 
@@ -1199,12 +1203,6 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// backward arithmetic: 0 = exact fp32 MFMA, 1 = bf16 x 3 split products (snn_set_backward_precision)
-static int g_backward_split = 1;
-// forward arithmetic: 4 = fp16 x 3 (default; fp32-grade for |x| < 4094, |w| < 255), 3 = bf16 x 6 (fp32-grade, any
-// range), 0 = exact fp32 MFMA
-static int g_forward_split = 4;
-
 template <bool DGRAD, int SPLIT>
 static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
                          int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
@@ -1212,7 +1210,7 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(g.Mtot < 0x7fffffffLL && (int64_t)g.IH * g.IW < 0x7fffffffLL, "%s: too many pixels", name);
     const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
-    static const bool no_fast = getenv("SNN_CONV_NO_FAST") != nullptr;  // tuning / bisecting aid
+    static const bool no_fast = snn_tuning_env("SNN_CONV_NO_FAST") != nullptr;  // tuning / bisecting aid
     const bool fast = vec && !no_fast && g.IC % BK == 0 && ntaps >= 1 && ntaps <= 31 &&
                       (DGRAD ? g.nkh : g.KH) <= 6 && (DGRAD ? g.nkw : g.KW) <= 6 &&
                       (int64_t)g.IH * g.IW * g.ldi * 16 < 0x7fffffffLL && (int64_t)g.OC * g.KtotFull * 4 < 0x7fffffffLL;
@@ -1604,10 +1602,10 @@ template <bool FLIP>
 static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* out, int64_t ldo, int64_t N, int H,
                           int W, int IC, int OC, int split, const float* addend, int64_t ld_add,
                           const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
-    static const bool off = getenv("SNN_CONV_NO_DIRECT") != nullptr;  // tuning / bisecting aid
+    static const bool off = snn_tuning_env("SNN_CONV_NO_DIRECT") != nullptr;  // tuning / bisecting aid
     // measured: a win (12-15 %) for <= 32 output channels; at 64 the implicit-GEMM kernel is as fast or faster
     // (both are bound by LDS operand traffic there), so it stays the default; SNN_CONV_DIRECT_MAX_OC=64 to compare
-    static const int max_oc = getenv("SNN_CONV_DIRECT_MAX_OC") ? atoi(getenv("SNN_CONV_DIRECT_MAX_OC")) : 32;
+    static const int max_oc = snn_tuning_env("SNN_CONV_DIRECT_MAX_OC") ? atoi(snn_tuning_env("SNN_CONV_DIRECT_MAX_OC")) : 32;
     if (off || (split != 2 && split != 3 && split != 4) || IC % BK != 0 || OC > max_oc || OC > 64 || OC % 4 != 0) return -1;
     if (ldi % 4 != 0 || !aligned16(in) || !aligned16(wk)) return -1;
     if ((int64_t)H * W * ldi * 4 >= 0x7fffffffLL || (int64_t)OC * 9 * IC * 4 >= 0x7fffffffLL) return -1;
@@ -1626,7 +1624,7 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
     // persistent: at most (CUs per XCD) x (resident blocks per CU) blocks per XCD
     const int resident = (OC <= 32 && split != 3) ? 3 : 2;
-    int nbx = (SNN_NUM_CU / 8) * resident;
+    int nbx = (snn_num_cu() / 8) * resident;
     if (nbx > g.tiles_per_xcd) nbx = g.tiles_per_xcd;
     dim3 grid((unsigned)(nbx * 8));
 #define SNN_DIRECT_LAUNCH(BN_, WM_, WN_, SPLIT_, TPS_)                                                            \
@@ -1661,20 +1659,6 @@ static int check_conv_shape(const char* name, int64_t N, int H, int W, int Cin, 
 }
 
 }  // namespace
-
-extern "C" int snn_set_backward_precision(int mode) {
-    SNN_REQUIRE(mode == 0 || mode == 1, "snn_set_backward_precision: mode must be 0 (fp32) or 1 (bf16x3)");
-    g_backward_split = mode;
-    return 0;
-}
-extern "C" int snn_get_backward_precision(void) { return g_backward_split; }
-extern "C" int snn_set_forward_precision(int mode) {
-    SNN_REQUIRE(mode == 0 || mode == 3 || mode == 4,
-                "snn_set_forward_precision: mode must be 0 (fp32), 3 (bf16x6) or 4 (fp16x3)");
-    g_forward_split = mode;
-    return 0;
-}
-extern "C" int snn_get_forward_precision(void) { return g_forward_split; }
 
 // ------------------------------------------------------------------------------------------ first layer
 // The convolution over the 2-channel event frames (Cin = 2, 3x3: K = 18) does not belong on the matrix pipe
@@ -1791,22 +1775,25 @@ static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7
 
 // the shapes the two kernels above take: the caller checks alignment of its buffers on top
 static bool first_layer_shape(int Cin, int Cout, int KH, int KW) {
-    static const bool off = getenv("SNN_CONV_NO_FIRST") != nullptr;  // tuning / bisecting aid
+    static const bool off = snn_tuning_env("SNN_CONV_NO_FIRST") != nullptr;  // tuning / bisecting aid
     if (off || Cin != 2 || KH != 3 || KW != 3 || Cout % 4 != 0 || Cout > 256) return false;
     const int cgs = Cout / 4;
     return (cgs & (cgs - 1)) == 0;
 }
 
 static int first_layer_blocks(int64_t rows) {  // grid of the row-walking kernels = slabs of the weight gradient
-    int64_t b = rows < 4 * SNN_NUM_CU ? rows : 4 * SNN_NUM_CU;
+    int64_t b = rows < 4 * snn_num_cu() ? rows : 4 * snn_num_cu();
     return b < 1 ? 1 : (int)b;
 }
 }  // namespace
 
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                              const float* addend, int64_t ld_addend, void* stream) {
+                              const float* addend, int64_t ld_addend, int precision, void* stream) {
     SNN_REQUIRE(x && w && y, "snn_conv2d_fwd: null pointer");
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3,
+                "snn_conv2d_fwd: precision must be SNN_PREC_FP32, SNN_PREC_BF16X6 or SNN_PREC_FP16X3 (got %d)", precision);
+    const int fwd_split = precision;
     if (check_conv_shape("snn_conv2d_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout, "snn_conv2d_fwd: pixel stride smaller than channel count");
     ConvGeom g;
@@ -1826,20 +1813,20 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
         (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
         FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
-        const int blocks = fg.rows < 8 * SNN_NUM_CU ? fg.rows : 8 * SNN_NUM_CU;
+        const int blocks = fg.rows < 8 * snn_num_cu() ? fg.rows : 8 * snn_num_cu();
         hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
                            (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_fwd");
         return 0;
     }
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
-        const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, g_forward_split, addend, ld_addend,
+        const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, fwd_split, addend, ld_addend,
                                              nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
         if (rc >= 0) return rc;
     }
-    if (g_forward_split == 4)
+    if (fwd_split == 4)
         return launch_gather<false, 4>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
-    if (g_forward_split == 3)
+    if (fwd_split == 3)
         return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
 }
@@ -1847,8 +1834,11 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
 extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                                 const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2,
-                                void* stream) {
+                                int precision, void* stream) {
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3,
+                "snn_conv2d_dgrad: precision must be SNN_PREC_FP32 or SNN_PREC_BF16X3 (got %d)", precision);
+    const int bwd_split = precision;
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv2d_dgrad: addend2 pixel stride smaller than channel count");
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(lddy >= Cout && lddx >= Cin, "snn_conv2d_dgrad: pixel stride smaller than channel count");
@@ -1862,7 +1852,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     g.nimg = (int)N;
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
-    const bool split = g_backward_split != 0;
+    const bool split = bwd_split != 0;
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {  // dx = conv(dy, mirrored taps of w^T)
         const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
                                             ld_addend, addend2, ld_addend2, (hipStream_t)stream, "snn_conv2d_dgrad");
@@ -1897,7 +1887,7 @@ static WgradTile wgrad_tile(int Cout, int Ktot, bool split, int64_t M) {
     // blocks_per_cu: residency of each variant (registers / LDS), used to size the pixel split to ONE full wave
     static const WgradTile cand[] = {{128, 128, 0, 3}, {64, 256, 1, 3}, {32, 256, 2, 4},
                                      {128, 64, 3, 3},  {64, 64, 4, 3},  {32, 128, 5, 3}};
-    if (const char* force = getenv("SNN_WGRAD_TILE")) {  // tuning aid
+    if (const char* force = snn_tuning_env("SNN_WGRAD_TILE")) {  // tuning aid
         int id = atoi(force);
         if (id >= 0 && id < 6) return cand[id];
     }
@@ -1920,12 +1910,13 @@ static WgradTile wgrad_tile(int Cout, int Ktot, bool split, int64_t M) {
 }
 }  // namespace
 
-extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int precision) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
+    const int bwd_split = precision == SNN_PREC_FP32 ? 0 : 1;
     const int64_t M = N * Ho * (int64_t)Wo;
     const int64_t Ktot = (int64_t)KH * KW * Cin;
     if (first_layer_shape(Cin, Cout, KH, KW)) return first_layer_blocks(N * Ho);  // one slab per block
-    const bool split_mode = g_backward_split && Cin % 4 == 0 && Cout % 4 == 0;
+    const bool split_mode = bwd_split && Cin % 4 == 0 && Cout % 4 == 0;
     const WgradTile t = wgrad_tile(Cout, (int)Ktot, split_mode, M);
     const int64_t tiles = snn_ceil_div(Cout, t.bm) * snn_ceil_div(Ktot, t.bn);
     // all blocks resident at once (a second, nearly empty wave of equal-length blocks would double the time);
@@ -1936,12 +1927,12 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
     if (split_mode && t.id == 4) resident = KH * KW > 1 ? 4 : 2;
     if (split_mode && t.id == 0) {
         // three blocks per CU only while a split keeps >= 24 stages of 32 pixels; shorter splits are all prologue
-        const int64_t s3 = (3 * (int64_t)SNN_NUM_CU) / tiles;
+        const int64_t s3 = (3 * (int64_t)snn_num_cu()) / tiles;
         const int64_t s3r = s3 >= 32 ? s3 / 8 * 8 : (s3 < 1 ? 1 : s3);
         if (M / s3r < 24 * WB_K) resident = 2;
     }
-    if (const char* force = getenv("SNN_WGRAD_RESIDENT")) resident = atoi(force) > 0 ? atoi(force) : resident;  // tuning aid
-    int64_t s = ((int64_t)resident * SNN_NUM_CU) / tiles;
+    if (const char* force = snn_tuning_env("SNN_WGRAD_RESIDENT")) resident = atoi(force) > 0 ? atoi(force) : resident;  // tuning aid
+    int64_t s = ((int64_t)resident * snn_num_cu()) / tiles;
     const int64_t max_by_work = snn_ceil_div(M, 8 * WB_K);            // >= 8 LDS stages per block
     const int64_t max_by_mem = (int64_t)(64 << 20) / (Cout * Ktot);   // workspace <= 256 MiB
     if (s > max_by_work) s = max_by_work;
@@ -1968,8 +1959,11 @@ static int wgrad_reduce_slabs(const float* workspace, float* dw, int64_t n, int 
 
 extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                                int accumulate, float* workspace, int splitk, void* stream) {
+                                int accumulate, float* workspace, int splitk, int precision, void* stream) {
     SNN_REQUIRE(x && dy && dw && workspace, "snn_conv2d_wgrad: null pointer");
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3,
+                "snn_conv2d_wgrad: precision must be SNN_PREC_FP32 or SNN_PREC_BF16X3 (got %d)", precision);
+    const int bwd_split = precision;
     if (check_conv_shape("snn_conv2d_wgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && lddy >= Cout, "snn_conv2d_wgrad: pixel stride smaller than channel count");
     SNN_REQUIRE(splitk >= 1 && splitk <= 32768, "snn_conv2d_wgrad: bad splitk %d", splitk);
@@ -1991,16 +1985,16 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     }
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);
-    const WgradTile t = wgrad_tile(Cout, g.Ktot, g_backward_split && Cin % 4 == 0 && Cout % 4 == 0, g.Mtot);
+    const WgradTile t = wgrad_tile(Cout, g.Ktot, bwd_split && Cin % 4 == 0 && Cout % 4 == 0, g.Mtot);
     // small tiles (64 x 64, 32 x 128) run 64-pixel stages in the pipelined kernel (latency cover), the others 32
-    static const int wbk_small = getenv("SNN_WGRAD_WBK") ? atoi(getenv("SNN_WGRAD_WBK")) : 64;  // tuning aid
+    static const int wbk_small = snn_tuning_env("SNN_WGRAD_WBK") ? atoi(snn_tuning_env("SNN_WGRAD_WBK")) : 64;  // tuning aid
     const int wbk = (t.id >= 4 && wbk_small == 64) ? 64 : 32;
     g.pix_per_split = snn_ceil_div(snn_ceil_div(g.Mtot, splitk), wbk) * wbk;
     g.nimg = (int)N;
     // pipelined kernel: 32-bit byte offsets relative to the first image of a pixel split
     const int64_t span_pix = g.pix_per_split * (int64_t)stride * stride + 3 * (int64_t)H * W;
-    static const bool no_pipe = getenv("SNN_WGRAD_NO_PIPE") != nullptr;  // tuning / bisecting aid
-    const bool pipe = vec && g_backward_split && !no_pipe && g.Mtot < 0x7fffffffLL && span_pix * ldx * 4 < 0x7fffffffLL &&
+    static const bool no_pipe = snn_tuning_env("SNN_WGRAD_NO_PIPE") != nullptr;  // tuning / bisecting aid
+    const bool pipe = vec && bwd_split && !no_pipe && g.Mtot < 0x7fffffffLL && span_pix * ldx * 4 < 0x7fffffffLL &&
                       g.pix_per_split * lddy * 4 < 0x7fffffffLL && (int64_t)H * W * ldx * 4 < 0x7fffffffLL;
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);

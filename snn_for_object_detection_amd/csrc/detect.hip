@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms_sorted(const float* __restr
             __syncthreads();
             if (live)
                 for (int j = 0; j < m; ++j)
-                    if (iou_of(ktile[j], mine) > thr) {
+                    if (!(iou_of(ktile[j], mine) <= thr)) {  // the reference KEEPS iou <= thr (box.py:95-97): a NaN IoU suppresses
                         live = false;
                         break;
                     }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms_sorted(const float* __restr
         unsigned long long m4[kNmsThreads / 64] = {0ull, 0ull, 0ull, 0ull};
         if (tid < n)
             for (int j = tid + 1; j < n; ++j)
-                if (iou_of(mine, cand[j]) > thr) m4[j >> 6] |= 1ull << (j & 63);
+                if (!(iou_of(mine, cand[j]) <= thr)) m4[j >> 6] |= 1ull << (j & 63);
 #pragma unroll
         for (int w = 0; w < kNmsThreads / 64; ++w) mask[tid][w] = m4[w];
         __syncthreads();

@@ -23,7 +23,7 @@ constexpr int kThreads = 256;
 
 static unsigned grid_for(int64_t n) {
     int64_t b = snn_ceil_div(n, kThreads);
-    if (b > SNN_MAX_BLOCKS) b = SNN_MAX_BLOCKS;
+    if (b > snn_max_blocks()) b = snn_max_blocks();
     if (b < 1) b = 1;
     return (unsigned)b;
 }

@@ -44,7 +44,7 @@ static StatsPlan stats_plan(int T, int64_t M, int C) {
     pl.cvb = cv < kThreads ? cv : kThreads;
     pl.zblocks = (int)snn_ceil_div(cv, pl.cvb);
     int P = kThreads / pl.cvb;
-    int64_t want = snn_ceil_div(SNN_MAX_BLOCKS, (int64_t)T * pl.zblocks);
+    int64_t want = snn_ceil_div(snn_max_blocks(), (int64_t)T * pl.zblocks);
     int64_t maxc = snn_ceil_div(M, (int64_t)P * 8);  // at least ~8 pixels per thread
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
@@ -406,8 +406,8 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     // time with the tail masked: all blocks are resident at once and finish together.  (A grid-stride loop over
     // kBwdNP-row groups left e.g. 713 groups on 512 blocks: 2 rounds for 1.4 rounds of work.)
     const int64_t rows = snn_ceil_div(M, (int64_t)P);
-    int64_t cap = with_sums ? 512 : SNN_MAX_BLOCKS;  // 64 KiB of LDS per block -> 2 blocks per CU
-    if (const char* force = getenv("SNN_BWD_CAP")) cap = atoi(force) > 0 ? atoi(force) : cap;  // tuning aid
+    int64_t cap = with_sums ? 2 * snn_num_cu() : snn_max_blocks();  // 64 KiB of LDS per block -> 2 blocks per CU
+    if (const char* force = snn_tuning_env("SNN_BWD_CAP")) cap = atoi(force) > 0 ? atoi(force) : cap;  // tuning aid
     cap = cap / pl.gy;
     if (cap < 1) cap = 1;
     const int64_t rpb = snn_ceil_div(rows, rows < cap ? rows : cap);
@@ -1146,7 +1146,7 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
     int64_t total = M * (C / vec);
     // every thread scans the same number of (pixel, channel group) items over all T (grid-stride, tail masked) and
     // all blocks are resident at once: a capped grid with 1.4 items per thread would run 2 rounds for 1.4 of work
-    const int64_t per_thread = snn_ceil_div(total, (int64_t)SNN_MAX_BLOCKS * kThreads);
+    const int64_t per_thread = snn_ceil_div(total, (int64_t)snn_max_blocks() * kThreads);
     int64_t blocks = snn_ceil_div(total, kThreads * per_thread);
     dim3 grid((unsigned)blocks);
     switch (neuron) {
@@ -1223,8 +1223,9 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
                                      int64_t ldy, const float* g_vT, const float* g_iT, const float* alpha,
                                      const float* beta, int apply_scale, float* gx, float* g_v0, float* g_i0,
                                      double* sums, int T, int64_t M, int C, const snn_neuron_params* p,
-                                     void* stream) {
+                                     int flags, void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
+    SNN_REQUIRE((flags & ~SNN_SCAN_WIDE_ADDRESSING) == 0, "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
     SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_bwd: bad neuron %d",
                 neuron);
@@ -1243,7 +1244,7 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     }
     dim3 grid(pl.gx, pl.gy);
     // buffer addressing (see k_affine_neuron_bwd): one timestep of every tensor must fit a 31-bit byte offset
-    const bool no_buf = getenv("SNN_BWD_NO_BUF") != nullptr;  // tuning / bisecting aid (read per call: tests flip it)
+    const bool no_buf = (flags & SNN_SCAN_WIDE_ADDRESSING) != 0;
     const int64_t ld_max = ldg > ldy ? (ldg > C ? ldg : C) : (ldy > C ? ldy : C);
     // (blocks with a single pixel row take the one-pixel-per-thread instance: the three empty pixel slots of the
     // four-pixel one are computed and issued in straight-line code - measured 58 us against 45 for the branchy kernel)
@@ -1348,7 +1349,7 @@ extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, co
                   : 1;
     int64_t total = (int64_t)T * M * (C / vec);
     int64_t blocks = snn_ceil_div(total, kThreads);
-    if (blocks > SNN_MAX_BLOCKS) blocks = SNN_MAX_BLOCKS;
+    if (blocks > snn_max_blocks()) blocks = snn_max_blocks();
     if (vec == 4)
         hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y,
                            ldy, coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);

@@ -27,9 +27,31 @@ void snn_set_error(const char* fmt, ...);
 static inline int64_t snn_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int64_t snn_ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// MI355X: 256 CUs; memory-bound kernels cap the grid at 8 blocks/CU and grid-stride the rest.
-static constexpr int SNN_NUM_CU = 256;
-static constexpr int SNN_MAX_BLOCKS = SNN_NUM_CU * 8;
+// Compute units of the current device (MI355X: 256), asked once from the runtime.  Host-only planning helpers
+// (snn_conv2d_wgrad_splitk, *_size) may be called in a process without a device: they then plan for 256 CUs.
+// Memory-bound kernels cap the grid at 8 blocks / CU and grid-stride the rest.
+static inline int snn_num_cu() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) {
+        cached = n;
+        return n;
+    }
+    (void)hipGetLastError();  // no device in this process: not an error of the caller
+    return 256;
+}
+static inline int snn_max_blocks() { return snn_num_cu() * 8; }
+
+// Tuning / bisecting knobs exist only in builds made with -DSNN_TUNING (python -m snn_for_object_detection_amd._build
+// --tuning); the product library reads no environment variable.
+#ifdef SNN_TUNING
+#include <stdlib.h>
+static inline const char* snn_tuning_env(const char* name) { return getenv(name); }
+#else
+static inline const char* snn_tuning_env(const char*) { return nullptr; }
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

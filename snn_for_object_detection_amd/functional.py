@@ -34,39 +34,60 @@ def neuron_params(dt: float = DEFAULT_DT) -> NeuronParams:
 
 
 # ------------------------------------------------------------------------------------------- precision
-def set_backward_precision(mode: str) -> None:
-    """Arithmetic of the backward convolutions (data / weight gradients).
-
-    ``"bf16x3"`` (default): fp32 operands are split into bf16 hi + lo and multiplied as hi*hi + hi*lo + lo*hi on
-    the bf16 matrix cores with fp32 accumulation - relative error ~1e-5 of the exact product, 2-2.5x faster on
-    MFMA-bound shapes.  ``"fp32"``: exact fp32 MFMA (an fmaf chain)."""
-    modes = {"fp32": 0, "bf16x3": 1}
-    if mode not in modes:
-        raise ValueError(f"backward precision must be one of {sorted(modes)}")
-    _hip.call("snn_set_backward_precision", modes[mode])
-
-
-def get_backward_precision() -> str:
-    return ("fp32", "bf16x3")[_hip.query("snn_get_backward_precision")]
-
-
+# The arithmetic of a convolution is an argument of every C-ABI call (include/snn_hip.h, SNN_PREC_*): the library keeps
+# no arithmetic state.  What is kept HERE is the Python-side default that layers without their own setting use:
+#   forward : "fp16x3" (default: two fp16 pieces per operand after exact power-of-two pre-scaling, three products;
+#             fp32-grade for conv inputs |x| < 4094 and weights |w| < 255 - spikes and normalised activations),
+#             "bf16x6" (three bf16 pieces, six products: fp32-grade for any range, half the speed),
+#             "fp32"   (exact fp32 MFMA, an fmaf chain);
+#   backward: "bf16x3" (default: bf16 hi + lo, hi*hi + hi*lo + lo*hi, relative error ~1e-5 of the exact product),
+#             "fp32".
+# A layer overrides it with ``HipConv2d.forward_precision / .backward_precision`` (BlockGen sets "bf16x6" on
+# convolutions fed by an unbounded activation - ReLU / SiLU / SumPool / ConvLSTM - where the fp16 range contract of
+# "fp16x3" is not guaranteed by construction).
+FORWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x6": _hip.PREC_BF16X6, "fp16x3": _hip.PREC_FP16X3}
+BACKWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x3": _hip.PREC_BF16X3}
 DEFAULT_FORWARD_PRECISION = "fp16x3"
 DEFAULT_BACKWARD_PRECISION = "bf16x3"
 
 
+def _checked(mode: str, table: dict, what: str) -> str:
+    if mode not in table:
+        raise ValueError(f"{what} precision must be one of {sorted(table)}, got {mode!r}")
+    return mode
+
+
+# session defaults; SNN_FORWARD_PRECISION / SNN_BACKWARD_PRECISION preset them (validated here, not in the library)
+_forward_precision = _checked(os.environ.get("SNN_FORWARD_PRECISION") or DEFAULT_FORWARD_PRECISION, FORWARD_MODES,
+                              "SNN_FORWARD_PRECISION: forward")
+_backward_precision = _checked(os.environ.get("SNN_BACKWARD_PRECISION") or DEFAULT_BACKWARD_PRECISION, BACKWARD_MODES,
+                               "SNN_BACKWARD_PRECISION: backward")
+
+
 def set_forward_precision(mode: str) -> None:
-    """Forward convolution arithmetic (fp32 storage and accumulation in every mode): ``"fp16x3"`` (default: two
-    fp16 pieces per operand after exact power-of-two pre-scaling, three products; fp32-grade for conv inputs
-    |x| < 4094 and weights |w| < 255 - spikes and normalised activations), ``"bf16x6"`` (three bf16 pieces, six
-    products: fp32-grade for any range, half the speed) or ``"fp32"`` (exact fp32 MFMA, an fmaf chain)."""
-    modes = {"fp32": 0, "bf16x6": 3, "fp16x3": 4}
-    if mode not in modes:
-        raise ValueError(f"forward precision must be one of {sorted(modes)}")
-    _hip.call("snn_set_forward_precision", modes[mode])
+    """Default forward arithmetic of convolutions without their own ``forward_precision``."""
+    global _forward_precision
+    _forward_precision = _checked(mode, FORWARD_MODES, "forward")
 
 
 def get_forward_precision() -> str:
-    return {0: "fp32", 3: "bf16x6", 4: "fp16x3"}[_hip.query("snn_get_forward_precision")]
+    return _forward_precision
+
+
+def set_backward_precision(mode: str) -> None:
+    """Default arithmetic of the backward convolutions (data / weight gradients) without their own setting."""
+    global _backward_precision
+    _backward_precision = _checked(mode, BACKWARD_MODES, "backward")
+
+
+def get_backward_precision() -> str:
+    return _backward_precision
+
+
+def _prec_codes(forward: Optional[str], backward: Optional[str]) -> Tuple[int, int]:
+    """Per-call ``precision`` arguments: the layer's own modes, else the session defaults."""
+    return (FORWARD_MODES[_checked(forward or _forward_precision, FORWARD_MODES, "forward")],
+            BACKWARD_MODES[_checked(backward or _backward_precision, BACKWARD_MODES, "backward")])
 
 
 # ------------------------------------------------------------------------------------------- helpers
@@ -383,7 +404,7 @@ def _slot_of(param) -> Optional[GradSlot]:
 
 
 # ------------------------------------------------------------------------------------------- conv
-def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st):
+def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec):
     """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
     (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
     T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
@@ -417,7 +438,7 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st):
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
     _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
-              Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, st)
+              Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
     if acc is not None and (acc[0].result is None or chained):
         if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
             acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
@@ -436,8 +457,9 @@ class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None):
         _require_device(x, "conv2d input")
+        fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         _require_device(weight, "conv2d weight")
         T, B, Cin, H, W = _dims5(x)
         Cout, Cin_w, KH, KW = weight.shape
@@ -450,7 +472,8 @@ class _Conv2d(Function):
         w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
         y = _out_tensor(dest, T, B, Cout, Ho, Wo, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
-                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _stream())
+                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, fwd_prec, _stream())
+        ctx.prec = bwd_prec
         ctx.save_for_backward(x, w_ohwi)
         ctx.weight_ref = weight if getattr(weight, "_snn_wt", None) is not None else None  # FlatTrainer's cached w^T
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
@@ -473,9 +496,9 @@ class _Conv2d(Function):
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
-            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st)
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec)
         if ctx.needs_input_grad[1]:
-            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW)
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW, ctx.prec)
             if ctx.slot is not None and USE_WGRAD_STREAM:
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
@@ -486,19 +509,20 @@ class _Conv2d(Function):
                     ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                     _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(),
                               T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(),
-                              splitk, side.cuda_stream)
+                              splitk, ctx.prec, side.cuda_stream)
                 _side_hold(side, x, gy)
             elif ctx.slot is not None:
                 ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(), T * B,
-                          H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, st)
+                          H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk,
+                          ctx.prec, st)
             else:
                 ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
-                          W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, st)
+                          W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, ctx.prec, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 class _ComposedConv1x1(Function):
@@ -512,8 +536,9 @@ class _ComposedConv1x1(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w1, w2, slot1, slot2, dest, acc):
+    def forward(ctx, x, w1, w2, slot1, slot2, dest, acc, prec=None):
         _require_device(x, "conv2d input")
+        fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         T, B, Cin, H, W = _dims5(x)
         C1, C2 = w1.shape[0], w2.shape[0]
         if w1.shape[1] != Cin or w2.shape[1] != C1 or tuple(w1.shape[2:]) != (1, 1) or tuple(w2.shape[2:]) != (1, 1):
@@ -524,7 +549,8 @@ class _ComposedConv1x1(Function):
         wc = torch.mm(w2m, w1m).contiguous()                  # [C2, Cin] = OHWI of a 1x1 kernel
         y = _out_tensor(dest, T, B, C2, H, W, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
-                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, _stream())
+                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, fwd_prec, _stream())
+        ctx.prec = bwd_prec
         ctx.save_for_backward(x, w1m, w2m, wc)
         ctx.geom = (T, B, Cin, H, W, C2, 1, 1, H, W, 1, 0)
         ctx.c1 = C1
@@ -543,11 +569,11 @@ class _ComposedConv1x1(Function):
         dx = dw1 = dw2 = None
         if ctx.needs_input_grad[0]:
             wct = wc.t().contiguous()                         # [Cin, C2] = transposed 1x1 weight
-            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wct, x, ctx.geom, st)
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wct, x, ctx.geom, st, ctx.prec)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             slot1, slot2 = ctx.slots
             slotted = slot1 is not None and slot2 is not None
-            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, C2, 1, 1)
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, C2, 1, 1, ctx.prec)
             side_ok = slotted and USE_WGRAD_STREAM
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main
@@ -558,7 +584,7 @@ class _ComposedConv1x1(Function):
                 ws = torch.empty((splitk, C2 * Cin), device=x.device, dtype=_F32)
                 G = torch.empty((C2, Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
-                          W, C2, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, stream.cuda_stream)
+                          W, C2, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, ctx.prec, stream.cuda_stream)
                 g2 = torch.mm(G, w1m.t())                     # [C2, C1]
                 g1 = torch.mm(w2m.t(), G)                     # [C1, Cin]
                 if slotted:
@@ -572,19 +598,23 @@ class _ComposedConv1x1(Function):
                 _side_hold(stream, x, gy)
             if not slotted:
                 dw1, dw2 = g1.view(C1, Cin, 1, 1), g2.view(C2, C1, 1, 1)
-        return dx, dw1, dw2, None, None, None, None
+        return dx, dw1, dw2, None, None, None, None, None
 
 
-def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: Optional[Dest] = None) -> torch.Tensor:
+def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: Optional[Dest] = None,
+                     forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
     seq, single = as_sequence(x)
-    y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq))
+    y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq),
+                               _prec_codes(forward_precision, backward_precision))
     return y[0] if single else y
 
 
-def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
-           dest: Optional[Dest] = None) -> torch.Tensor:
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0, dest: Optional[Dest] = None,
+           forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
+    """``forward_precision`` / ``backward_precision``: this call's arithmetic (None = the session default)."""
     seq, single = as_sequence(x)
-    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq))
+    y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq),
+                      _prec_codes(forward_precision, backward_precision))
     return y[0] if single else y
 
 
@@ -604,6 +634,7 @@ class SynapseState(NamedTuple):
 
 
 _SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
+SCAN_FLAGS = 0   # flags of snn_affine_neuron_bwd; tests set _hip.SCAN_WIDE_ADDRESSING to cover the 64-bit-pointer scan
 
 # Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores
 # checkpoints of (v, i) every snn_lif_ckpt_interval() steps instead and recomputes in the backward scan
@@ -766,7 +797,7 @@ class _AffineNeuron(Function):
         else:
             _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy,
                       _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0),
-                      _ptr(g_i0), _ptr(sums), T, M, C, params, st)
+                      _ptr(g_i0), _ptr(sums), T, M, C, params, SCAN_FLAGS, st)
         dy = dgamma = dbias = None
         if need_sums:
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)

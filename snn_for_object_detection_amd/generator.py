@@ -26,8 +26,8 @@ from . import _hip
 from . import functional as HF
 from .anchors import AnchorGenerator
 from .layer_gen import *  # noqa: F401,F403  (the reference re-exports the layer generators here)
-from .layer_gen import (Dense, HipBatchNorm2d, HipConv2d, HipTanh, LayerGen, LICell, LIFCell, Residual, Return,
-                        SLICell, StateStorage, Storage, SynapseCell)
+from .layer_gen import (ConvLSTM, Dense, HipBatchNorm2d, HipConv2d, HipReLU, HipSiLU, HipTanh, LayerGen,
+                        LICell, LIFCell, Residual, Return, SLICell, StateStorage, Storage, SumPool2d, SynapseCell)
 
 ListGen = List[Union[LayerGen, "ListGen"]]
 ListState = List[Union[torch.Tensor, None, "ListState"]]
@@ -117,6 +117,12 @@ class BlockGen(nn.Module):
                 channels = layer.out_channels
             else:
                 layer, channels = layer_gen.get(channels)
+            # fp16x3 (the default forward arithmetic) has a range contract (|x| < 4094) that spikes, sums of spikes and
+            # normalised activations meet by construction; a convolution fed by an unbounded activation takes the
+            # any-range bf16x6 arithmetic instead (unless the description set a precision itself)
+            if (isinstance(layer, HipConv2d) and layer.forward_precision is None and layer_list
+                    and isinstance(layer_list[-1], (HipReLU, HipSiLU, SumPool2d, ConvLSTM))):
+                layer.forward_precision = "bf16x6"
             layer_list.append(layer)
             state_layers.append(_is_module_stateful(layer))
         return nn.ModuleList(layer_list), state_layers, channels
@@ -233,7 +239,10 @@ class BlockGen(nn.Module):
                 elif isinstance(layer, BlockGen):
                     Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise)
                 elif isinstance(layer, HipConv2d) and pre_conv is not None and k == 0:
-                    Y = HF.composed_conv1x1(Y, pre_conv.weight, layer.weight, dest=step_dest)
+                    Y = HF.composed_conv1x1(Y, pre_conv.weight, layer.weight, dest=step_dest,
+                                            forward_precision=pre_conv.forward_precision or layer.forward_precision,
+                                            backward_precision=(pre_conv.backward_precision
+                                                                or layer.backward_precision))
                 elif isinstance(layer, HipConv2d):
                     Y = layer(Y, dest=step_dest)
                 elif isinstance(layer, (LIFCell, LICell, SLICell, SynapseCell)):

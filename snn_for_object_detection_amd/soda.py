@@ -55,6 +55,7 @@ class SODa(nn.Module):
         self.box_loss = nn.L1Loss(reduction="none")
         # anchors of the last forward, keyed by the frame size: lets the next step compute its targets EARLY
         self._anchor_cache = {}
+        self._target_streams = {}
 
     # ------------------------------------------------------------------ description hooks
     def backbone_cfgs(self) -> ListGen:
@@ -106,8 +107,10 @@ class SODa(nn.Module):
         anchors = self._anchor_cache.get(key)
         if anchors is None or not X.is_cuda:
             return None
-        from . import functional as HF
-        main, side = torch.cuda.current_stream(), HF._side_stream(X.device)
+        main = torch.cuda.current_stream()
+        side = self._target_streams.get(X.device)
+        if side is None:  # a stream of its own: the weight-gradient side stream is busy with the previous backward
+            side = self._target_streams[X.device] = torch.cuda.Stream(device=X.device)
         side.wait_stream(main)  # the labels are ready
         with torch.cuda.stream(side):
             targets = self.roi_blk(anchors, labels)
@@ -159,21 +162,30 @@ class SODa(nn.Module):
               early=None) -> torch.Tensor:
         # soda.py:259-281
         anchors, cls_preds, bbox_preds = preds
-        if early is not None and early[0].shape == anchors.shape:
-            _, (bbox_offset, bbox_mask, class_labels), done = early
+        targets = None
+        if early is not None:
+            # ALWAYS join the target stream, also when its result is dropped: it read `labels`, which the main
+            # stream may free or overwrite from here on
+            early_anchors, targets, done = early
             main = torch.cuda.current_stream()
             main.wait_event(done)
-            for t in (bbox_offset, bbox_mask, class_labels):
-                t.record_stream(main)  # allocated on the side stream, consumed here
-        else:
-            bbox_offset, bbox_mask, class_labels = self.roi_blk(anchors, labels)
+            for t in targets:
+                t.record_stream(main)  # allocated on the side stream, consumed (or released) here
+            if early_anchors.shape != anchors.shape:
+                targets = None
+        if targets is None:
+            targets = self.roi_blk(anchors, labels)
+        bbox_offset, bbox_mask, class_labels = targets
         _, _, num_classes = cls_preds.shape
         cls = self.cls_loss.forward(cls_preds.reshape(-1, num_classes), class_labels.reshape(-1))
         bbox = self.box_loss.forward(bbox_preds * bbox_mask, bbox_offset * bbox_mask)
-        # masked means without boolean indexing (= cls[mask].mean(), cls[~mask].mean(); no host sync)
-        mask = (class_labels.reshape(-1) > 0).to(cls.dtype)
-        gt_loss = (cls * mask).sum() / mask.sum()
-        background_loss = (cls * (1 - mask)).sum() / (1 - mask).sum()
+        # masked means without boolean indexing (= cls[mask].mean(), cls[~mask].mean(); no host sync).  torch.where,
+        # not a product with the mask: a non-finite CE value at an anchor OUTSIDE a set must not reach that set's
+        # mean (0 * inf = NaN), exactly as the reference's boolean indexing ignores it
+        mask = class_labels.reshape(-1) > 0
+        zero = torch.zeros_like(cls)
+        gt_loss = torch.where(mask, cls, zero).sum() / mask.sum()
+        background_loss = torch.where(mask, zero, cls).sum() / (~mask).sum()
         return (gt_loss * self.hparams.loss_ratio + background_loss * (1 - self.hparams.loss_ratio) + bbox.mean())
 
     def spike_taps(self):

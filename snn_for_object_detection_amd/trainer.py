@@ -15,7 +15,7 @@ Here, per process (= per GPU):
 ``torch.distributed`` is the transport only (backend ``nccl`` = RCCL on ROCm, ``gloo`` in CPU tests).
 """
 
-from typing import Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -42,7 +42,7 @@ class FlatTrainer:
     """
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, use_grad_slots: bool = True):
+                 process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise RuntimeError("model has no trainable parameters")
@@ -86,6 +86,16 @@ class FlatTrainer:
                 self._conv_params.append(p)
             off += p.numel()
         self._wt_table = torch.tensor(table, dtype=torch.int64, device=dev) if table else None
+        self._offsets = [0]
+        for p in self.params:
+            self._offsets.append(self._offsets[-1] + p.numel())
+        # BatchNorm buffers (running statistics, num_batches_tracked).  Without SyncBatchNorm every rank updates them
+        # from its own shard; torch DDP (the reference's ``strategy: ddp``, config/config.yaml:35) broadcasts rank 0's
+        # buffers to all ranks (``broadcast_buffers=True``), so a checkpoint written by any rank holds the same
+        # statistics.  ``step()`` does the same with ONE broadcast of a flat copy (44 small tensors for TinyYolo).
+        self._float_buffers = [b for b in model.buffers() if b.is_floating_point()]
+        self._int_buffers = [b for b in model.buffers() if not b.is_floating_point() and b.numel() == 1]
+        self.broadcast_buffers = broadcast_buffers
         self.refresh_transposed_weights()
 
     def refresh_transposed_weights(self) -> None:
@@ -124,21 +134,112 @@ class FlatTrainer:
         if self.world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _written_ranges(self) -> List[Tuple[int, int]]:
+        """Element ranges of the flat buffers that received a gradient this step, adjacent parameters coalesced.
+        ``torch.optim.Adamax`` skips parameters whose ``.grad`` is None (their moments do not decay and the parameter
+        does not move); the fused kernel is launched per written range to keep that behaviour.  With data parallelism
+        a parameter counts as written when ANY rank wrote it (the all-reduce delivers the others' gradients)."""
+        written = [slot.written for slot in self.slots]
+        if self.world > 1 and not all(written):
+            flags = torch.tensor(written, dtype=torch.int32, device=self.flat_grad.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            written = [bool(f) for f in flags.tolist()]
+        if all(written):
+            return [(0, self.flat_param.numel())]   # the common case: one launch over the padded buffer
+        ranges: List[Tuple[int, int]] = []
+        for k, w in enumerate(written):
+            if not w:
+                continue
+            lo, hi = self._offsets[k], self._offsets[k + 1]
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1] = (ranges[-1][0], hi)
+            else:
+                ranges.append((lo, hi))
+        return ranges
+
+    def _check_bindings(self) -> None:
+        """``model.to(...)`` / ``model.float()`` / a manual ``p.data = ...`` would silently detach a parameter from
+        the flat buffer (the optimiser would then update memory the model no longer reads)."""
+        base = self.flat_param.data_ptr()
+        for k, p in enumerate(self.params):
+            if p.data_ptr() != base + 4 * self._offsets[k]:
+                raise RuntimeError("FlatTrainer: a parameter no longer lives in the flat parameter buffer (the model "
+                                   "was moved or re-cast after the trainer was built); build a new FlatTrainer")
+
+    def sync_buffers(self, src: int = 0) -> None:
+        """Rank ``src``'s BatchNorm buffers to every rank in one broadcast (torch DDP's ``broadcast_buffers``)."""
+        if self.world <= 1 or not (self._float_buffers or self._int_buffers):
+            return
+        flat = torch.cat([b.detach().reshape(-1).float() for b in self._float_buffers]
+                         + [b.detach().reshape(-1).float() for b in self._int_buffers])
+        dist.broadcast(flat, src=src, group=self.group)
+        off = 0
+        with torch.no_grad():
+            for b in self._float_buffers + self._int_buffers:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+                off += n
+
     def step(self) -> None:
-        if self.flat_param.is_cuda:
-            wgrad_stream_sync()  # weight-gradient kernels run on a side stream (functional._Conv2d.backward)
-        self._collect_autograd_grads()
-        self.all_reduce()
-        self.step_count += 1
-        if self.flat_param.is_cuda:
-            _hip.call("snn_adamax_step", self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-                      self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.flat_param.numel(), self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / self.world,
-                      torch.cuda.current_stream().cuda_stream)
-            self.refresh_transposed_weights()
-        else:
+        if not self.flat_param.is_cuda:
             raise RuntimeError("FlatTrainer.step: parameters are not on a HIP device; the optimiser kernel has no "
                                "CPU fallback")
+        wgrad_stream_sync()  # weight-gradient kernels run on a side stream (functional._Conv2d.backward)
+        self._check_bindings()
+        self._collect_autograd_grads()
+        ranges = self._written_ranges()
+        self.all_reduce()
+        self.step_count += 1
+        st = torch.cuda.current_stream().cuda_stream
+        for lo, hi in ranges:
+            _hip.call("snn_adamax_step", self.flat_param.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + 4 * lo,
+                      self.exp_avg.data_ptr() + 4 * lo, self.exp_inf.data_ptr() + 4 * lo, hi - lo, self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / self.world, st)
+        self.refresh_transposed_weights()
+        if self.broadcast_buffers:
+            self.sync_buffers()
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> Dict:
+        """Optimiser state in ``torch.optim.Adamax.state_dict()`` form: ``state[k] = {step, exp_avg, exp_inf}`` for the
+        k-th trainable parameter (tensors in the parameter's LOGICAL shape), one param group.  Interchangeable with a
+        ``torch.optim.Adamax`` built over the same parameter order (the reference's Lightning checkpoints carry that
+        state, ``models/soda.py:135-136``).  Weights and BatchNorm buffers are the model's own ``state_dict()``."""
+        state = {}
+        for k, p in enumerate(self.params):
+            state[k] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": _storage_view(self.exp_avg, self._offsets[k], p.data).clone(),
+                        "exp_inf": _storage_view(self.exp_inf, self._offsets[k], p.data).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "foreach": None,
+                 "maximize": False, "differentiable": False, "capturable": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise RuntimeError(f"optimizer state holds {len(group['params'])} parameters, the model has "
+                               f"{len(self.params)}")
+        if group.get("weight_decay", 0) or group.get("maximize", False):
+            raise RuntimeError("FlatTrainer: weight_decay / maximize are not supported by the fused Adamax kernel")
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_inf.zero_()
+        for k, p in enumerate(self.params):
+            st = sd["state"].get(k)
+            if st is None:  # torch creates a parameter's state at its first gradient
+                continue
+            for name, flat in (("exp_avg", self.exp_avg), ("exp_inf", self.exp_inf)):
+                t = st[name]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise RuntimeError(f"optimizer state {name}[{k}] has shape {tuple(t.shape)}, parameter "
+                                       f"{tuple(p.shape)}")
+                _storage_view(flat, self._offsets[k], p.data).copy_(t)
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise RuntimeError("FlatTrainer: per-parameter step counts differ; the fused kernel keeps one count")
+        self.step_count = steps.pop() if steps else 0
 
     # ------------------------------------------------------------------ helpers for tests / checkpoints
     def synchronize(self) -> None:

@@ -2,9 +2,11 @@
 
     python tests/golden/make_golden.py            # needs /root/reference
 
-Loads ``utils/box.py``, ``utils/anchors.py`` and ``utils/roi.py`` of the reference BY FILE PATH (the
-package ``__init__`` pulls in Lightning / OpenCV which are not installed), runs them on seeded inputs
-and stores inputs + outputs in ``tests/golden/detect_*.npz``.  Only data is stored - no reference
+Loads ``utils/box.py``, ``utils/anchors.py``, ``utils/roi.py`` and ``models/modules/conv_lstm.py`` of the
+reference BY FILE PATH (the package ``__init__`` files pull in Lightning / OpenCV / norse, which are not
+installed), runs them on seeded inputs and stores inputs + outputs in ``tests/golden/*.npz``.  The network
+DESCRIPTION ``models/tiny_yolo.py`` is executed against recording stand-ins of the layer generators (it only
+builds nested lists) and its structure stored as ``tiny_yolo_desc.json``.  Only data is stored - no reference
 source.  The fixtures pin ``oracle/detect.py`` and the product's ``anchors/box/roi`` modules
 (``tests/test_oracle_detect.py``).  ``/root/reference`` never travels to the GPU box; the fixtures do.
 """
@@ -59,6 +61,96 @@ def random_labels(gen, batch, n_boxes, n_classes, pad_rows=0):
             out[b, k, 0] = float(torch.randint(0, n_classes, (1,), generator=gen))
             out[b, k, 1:3], out[b, k, 3:5] = lo, hi
     return out
+
+
+def convlstm_golden(gen):
+    """``models/modules/conv_lstm.py:51-78``: seeded input sequence -> (h, c) after each of 3 steps, plus the
+    gradients of a seeded scalar loss w.r.t. the inputs and the gate weight (pins the oracle's restatement and the
+    HIP ``LSTM()`` layer)."""
+    mod = _load("ref_conv_lstm", os.path.join(REF, "models", "modules", "conv_lstm.py"))
+    T, B, Cin, Ch, H, W = 3, 2, 5, 4, 6, 7
+    cell = mod.ConvLSTM(Cin, Ch)
+    w = 0.5 * torch.randn(cell.conv.weight.shape, generator=gen)
+    with torch.no_grad():
+        cell.conv.weight.copy_(w)
+    x = torch.randn(T, B, Cin, H, W, generator=gen).requires_grad_()
+    gh = torch.randn(T, B, Ch, H, W, generator=gen)
+    gc = torch.randn(B, Ch, H, W, generator=gen)
+    state, hs, cs = None, [], []
+    for t in range(T):
+        h, state = cell(x[t], state)
+        hs.append(h)
+        cs.append(state[1])
+    loss = (torch.stack(hs) * gh).sum() + (state[1] * gc).sum()
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "convlstm.npz"), weight=w.numpy(), x=x.detach().numpy(), gh=gh.numpy(),
+                        gc=gc.numpy(), h=torch.stack(hs).detach().numpy(), c=torch.stack(cs).detach().numpy(),
+                        gx=x.grad.numpy(), gw=cell.conv.weight.grad.numpy())
+
+
+def tiny_yolo_description():
+    """Execute ``models/tiny_yolo.py`` with recording stand-ins for ``models.soda.SODa`` / ``models.generator`` /
+    ``models.modules`` (the real ones need Lightning, norse and python >= 3.12): the file only BUILDS nested lists of
+    layer generators, so the stand-ins record class name + constructor arguments.  Output: the nested structure of
+    ``backbone_cfgs() / neck_cfgs() / head_cfgs(36, 27)`` as JSON - data that pins the product's transcription of
+    the description independently of the oracle."""
+    import json
+
+    def recorder(kind, defaults):
+        class _Gen:
+            def __init__(self, *args, **kwargs):
+                vals = dict(defaults)
+                for k, v in zip(list(defaults), args):
+                    vals[k] = v
+                vals.update(kwargs)
+                self.kind, self.vals = kind, vals
+        _Gen.__name__ = kind
+        return _Gen
+
+    spec = {  # constructor signatures of models/modules/layer_gen.py:96-347
+        "Pass": {}, "Conv": {"out_channels": None, "kernel_size": 3, "stride": 1}, "Norm": {"bias": False},
+        "LIF": {"state_storage": False}, "LI": {"state_storage": False}, "ReLU": {}, "SiLU": {}, "Tanh": {},
+        "LSTM": {"hidden_size": None}, "Pool": {"type": None, "kernel_size": 2, "stride": None},
+        "Up": {"scale": 2, "mode": "nearest"}, "Return": {}, "Synapse": {}, "SLI": {"state_storage": False},
+    }
+    modules = types.ModuleType("models.modules")
+    for kind, defaults in spec.items():
+        setattr(modules, kind, recorder(kind, defaults))
+    modules.Residual = type("Residual", (list,), {})
+    modules.Dense = type("Dense", (list,), {})
+    modules.__all__ = list(spec) + ["Residual", "Dense"]
+    soda = types.ModuleType("models.soda")
+
+    class SODa:  # only what the description touches: self.hparams.state_storage
+        def __init__(self, state_storage=False):
+            self.hparams = types.SimpleNamespace(state_storage=state_storage)
+    soda.SODa = SODa
+    generator = types.ModuleType("models.generator")
+    generator.ListGen = list
+    pkg = types.ModuleType("models")
+    pkg.__path__ = []
+    saved = {k: sys.modules.get(k) for k in ("models", "models.soda", "models.generator", "models.modules")}
+    sys.modules.update({"models": pkg, "models.soda": soda, "models.generator": generator, "models.modules": modules})
+    try:
+        ty = _load("ref_tiny_yolo", os.path.join(REF, "models", "tiny_yolo.py"))
+        net = ty.TinyYolo()
+
+        def render(item):
+            if isinstance(item, (list, tuple)):
+                tag = type(item).__name__ if type(item).__name__ in ("Residual", "Dense") else "list"
+                return {"merge": tag, "items": [render(i) for i in item]}
+            return {"layer": item.kind, **item.vals}
+
+        desc = {"backbone": render(net.backbone_cfgs()), "neck": render(net.neck_cfgs()),
+                "head": render(net.head_cfgs(36, 27))}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    with open(os.path.join(OUT, "tiny_yolo_desc.json"), "w") as f:
+        json.dump(desc, f, indent=0, sort_keys=True)
 
 
 def main():
@@ -126,6 +218,8 @@ def main():
     det = box.multibox_detection(probs.clone(), offp.clone(), anc_m)
     np.savez_compressed(os.path.join(OUT, "detect_nms_mid.npz"), anchors=anc_m.numpy(), probs=probs.numpy(),
                         offsets=offp.numpy(), detections=det.numpy())
+    convlstm_golden(gen)
+    tiny_yolo_description()
     print("golden vectors written to", OUT)
 
 

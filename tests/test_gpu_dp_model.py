@@ -1,0 +1,135 @@
+"""Data-parallel TRAINING STEP of the model: two ranks, each with its own shard of the batch, run
+TinyYolo forward + loss + BPTT backward through ``FlatTrainer.step()`` (flat-gradient all-reduce, 1/world inside the
+fused Adamax) and must reproduce the 2-rank CPU restatement of the reference's DDP step:
+
+* without SyncBatchNorm: two oracle replicas, one shard each, per-rank loss means, gradients averaged
+  (``config/config.yaml:34-37``);
+* with SyncBatchNorm (``config/config.yaml:76``): batch statistics of the GLOBAL batch per timestep, per-rank loss
+  means, gradients averaged - restated as one oracle pass over the concatenated batch whose loss is the mean of
+  the two shard losses.
+
+Both ranks share the one GPU of the test box and exchange through gloo (fresh child processes; nothing is re-exec'd
+after the GPU was initialised); the production transport is RCCL, which needs one GPU per rank.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import rel_err, synthetic_events, synthetic_labels
+
+pytestmark = pytest.mark.gpu
+T, B_RANK, H, W = 4, 2, 32, 48
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard(rank):
+    return (synthetic_events(T, B_RANK, H, W, p=0.08, seed=10 + rank), synthetic_labels(B_RANK, seed=20 + rank))
+
+
+def _worker(rank, world, port, out_dir, sync_bn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters, convert_sync_batchnorm
+        torch.manual_seed(100 + rank)            # ranks start from different weights; the broadcast aligns them
+        model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+        tr = FlatTrainer(model, lr=1e-3)
+        broadcast_parameters(tr)
+        if sync_bn:
+            convert_sync_batchnorm(model)
+        start = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        X, labels = _shard(rank)
+        tr.zero_grad()
+        loss = model.training_step((X.cuda(), labels.cuda()))
+        loss.backward()
+        tr.synchronize()
+        local = {n: g.detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
+        tr.step()
+        torch.cuda.synchronize()
+        avg = {n: (g / world).detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
+        torch.save({"start": start, "loss": loss.item(), "local": local, "avg": avg,
+                    "after": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                    "backend": dist.get_backend(), "world": dist.get_world_size()},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sync_bn", [False, True], ids=["rank-local-bn", "sync-bn"])
+def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, sync_bn):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import snn_for_object_detection_amd as S
+    from oracle.net import SODaRef
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), sync_bn), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    assert r[0]["world"] == 2
+    for k in r[0]["start"]:                                   # broadcast from rank 0
+        assert torch.equal(r[0]["start"][k], r[1]["start"][k]), k
+
+    desc = S.TinyYolo(num_classes=2, time_window=0)
+    shards = [_shard(k) for k in range(world)]
+
+    def oracle_replica():
+        o = SODaRef(desc, 2, time_window=0)
+        o.load_state_dict(r[0]["start"])
+        return o.train()
+
+    if not sync_bn:
+        replicas, losses = [oracle_replica() for _ in range(world)], []
+        for o, (X, labels) in zip(replicas, shards):
+            loss = o.training_step((X, labels))
+            loss.backward()
+            losses.append(loss.item())
+        want = {n: sum(dict(o.named_parameters())[n].grad for o in replicas) / world
+                for n, _ in replicas[0].named_parameters()}
+        bn_ref = replicas[0]          # rank 0's buffers are what every rank holds after the step (DDP broadcast_buffers)
+    else:
+        o = oracle_replica()
+        X = torch.cat([s[0] for s in shards], dim=1)
+        preds = o(X)                                          # BatchNorm over the global batch, per timestep
+        losses = []
+        for k, (_, labels) in enumerate(shards):
+            sl = slice(k * B_RANK, (k + 1) * B_RANK)
+            losses.append(o._loss((preds[0], preds[1][sl], preds[2][sl]), labels))
+        (sum(losses) / world).backward()
+        losses = [l.item() for l in losses]
+        want = {n: p.grad for n, p in o.named_parameters()}
+        bn_ref = o
+    for k in range(world):
+        assert abs(r[k]["loss"] - losses[k]) <= 1e-4 * abs(losses[k]), (k, r[k]["loss"], losses[k])
+    worst = 0.0
+    for n, g in want.items():
+        if g is not None and g.norm() > 1e-8:
+            assert torch.equal(r[0]["avg"][n], r[1]["avg"][n]), n            # one all-reduce: identical on both ranks
+            worst = max(worst, rel_err(r[0]["avg"][n], g))
+    assert worst < 1e-3, worst
+    # the optimiser step: torch.optim.Adamax on the oracle's averaged gradient, from the same start
+    params = {n: torch.nn.Parameter(r[0]["start"][n].clone()) for n in want}
+    for n, p in params.items():
+        p.grad = want[n].clone()
+    torch.optim.Adamax(list(params.values()), lr=1e-3).step()
+    for n, p in params.items():
+        assert torch.equal(r[0]["after"][n], r[1]["after"][n]), n
+        assert rel_err(r[0]["after"][n], p.detach()) < 1e-5, n
+    # BatchNorm buffers: identical on both ranks after the step, equal to the restatement's
+    ref_sd = bn_ref.state_dict()
+    for k, v in r[0]["after"].items():
+        if "running_" in k or "num_batches_tracked" in k:
+            assert torch.equal(v, r[1]["after"][k]), k
+            if v.is_floating_point():
+                assert rel_err(v, ref_sd[k]) < 1e-5, k
+            else:
+                assert int(v) == int(ref_sd[k]) == T, k

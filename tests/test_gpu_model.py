@@ -34,9 +34,15 @@ def test_tiny_yolo_train_step_matches_oracle(S, fwd, bwd):
         S.functional.set_backward_precision(S.functional.DEFAULT_BACKWARD_PRECISION)
 
 
-def _train_step_vs_oracle(S, T, B, H, W):
+def test_tiny_yolo_train_step_with_padded_labels_matches_oracle(S):
+    """Labels padded with -1 rows (``utils/datasets.py:127-135``): the reference's RoI gives every padding ROW an anchor
+    too (class 0 but bbox mask 1, SURVEY a-11) - the device target assignment and loss must reproduce that quirk."""
+    _train_step_vs_oracle(S, 4, 2, 32, 48, pad_rows=2)
+
+
+def _train_step_vs_oracle(S, T, B, H, W, pad_rows=0):
     product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
-    X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B)
+    X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B, pad_rows=pad_rows)
     product.train()
     oracle.train()
     loss_ref = oracle.training_step((X, labels))

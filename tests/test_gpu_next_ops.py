@@ -1,5 +1,8 @@
 """Remaining operator API on the device against the oracle restatements of the
 reference's own cells: SLI (sli.py:80-126), Synapse (synapse.py:39-103), ConvLSTM (conv_lstm.py:10-78)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -98,3 +101,27 @@ def test_conv_lstm_matches_reference(S):
     assert rel_err(std[0][2][1], state[0][2][1]) < 1e-5           # final cell state
     for pd, pr in zip(blk.parameters(), ref.parameters()):
         assert rel_err(pd.grad, pr.grad) < 1e-4
+
+
+def test_conv_lstm_matches_reference_vectors(S, golden_dir):
+    """The HIP ``LSTM()`` layer against vectors produced by the reference's own ``models/modules/conv_lstm.py:51-78``
+    (tests/golden/make_golden.py): hidden / cell states of 3 steps and the gradients of a seeded loss."""
+    from snn_for_object_detection_amd.layer_gen import ConvLSTM
+    z = np.load(os.path.join(golden_dir, "convlstm.npz"))
+    x = torch.from_numpy(z["x"]).cuda().requires_grad_()
+    T, B, Cin = x.shape[:3]
+    Ch = z["h"].shape[2]
+    cell = ConvLSTM(Cin, Ch).cuda()
+    with torch.no_grad():
+        cell.conv.weight.copy_(torch.from_numpy(z["weight"]).cuda())
+    hs, (h_last, c_last) = cell(x)                       # whole sequence
+    assert rel_err(hs, torch.from_numpy(z["h"])) < 1e-5 and rel_err(c_last, torch.from_numpy(z["c"][-1])) < 1e-5
+    ((hs * torch.from_numpy(z["gh"]).cuda()).sum() + (c_last * torch.from_numpy(z["gc"]).cuda()).sum()).backward()
+    assert rel_err(x.grad, torch.from_numpy(z["gx"])) < 1e-4
+    assert rel_err(cell.conv.weight.grad, torch.from_numpy(z["gw"])) < 1e-4
+    state, cs = None, []                                 # reference protocol: one timestep at a time
+    with torch.no_grad():
+        for t in range(T):
+            h, state = cell(x[t].detach(), state)
+            cs.append(state[1])
+    assert rel_err(torch.stack(cs), torch.from_numpy(z["c"])) < 1e-5

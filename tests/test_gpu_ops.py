@@ -98,12 +98,15 @@ def test_dgrad_two_fused_addends(HF, hip_lib):
         fused = torch.empty_like(plain)
         args = (dy.data_ptr(), Cout, wt.data_ptr())
         geom = (N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad)
-        _hip.call("snn_conv2d_dgrad", *args, plain.data_ptr(), Cin, *geom, None, 0, None, 0, st)
+        prec = _hip.PREC_BF16X3   # the arithmetic is an argument of every call (ABI v5)
+        _hip.call("snn_conv2d_dgrad", *args, plain.data_ptr(), Cin, *geom, None, 0, None, 0, prec, st)
         _hip.call("snn_conv2d_dgrad", *args, fused.data_ptr(), Cin, *geom, a1.data_ptr(), Cin + 8, a2.data_ptr(),
-                  2 * Cin, st)
+                  2 * Cin, prec, st)
         assert torch.equal(fused, (plain + a1) + a2)
         only2 = torch.empty_like(plain)
-        _hip.call("snn_conv2d_dgrad", *args, only2.data_ptr(), Cin, *geom, None, 0, a2.data_ptr(), 2 * Cin, st)
+        _hip.call("snn_conv2d_dgrad", *args, only2.data_ptr(), Cin, *geom, None, 0, a2.data_ptr(), 2 * Cin, prec, st)
+        with pytest.raises(RuntimeError, match="precision"):   # a forward-only mode is refused, loudly
+            _hip.call("snn_conv2d_dgrad", *args, only2.data_ptr(), Cin, *geom, None, 0, None, 0, _hip.PREC_FP16X3, st)
         assert torch.equal(only2, plain + a2)
 
 
@@ -187,11 +190,11 @@ def test_checkpointed_lif_is_bit_identical(HF, C, H, W, T, B, with_bn):
 
 @pytest.mark.parametrize("C,H,W,T,B", [(64, 60, 76, 4, 5), (24, 96, 120, 3, 2), (256, 30, 38, 2, 3)])
 def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
-    """Layers with several pixel rows per block take the buffer-addressed, branch-free backward scan; SNN_BWD_NO_BUF
-    forces the pointer / per-pixel-branch kernel.  Same arithmetic in the same order: every gradient must agree bit
+    """Layers with several pixel rows per block take the buffer-addressed, branch-free backward scan; the call flag
+    SNN_SCAN_WIDE_ADDRESSING forces the pointer / per-pixel-branch kernel (the library picks it by itself for tensors
+    whose timestep exceeds the 31-bit buffer offsets).  Same arithmetic in the same order: every gradient must agree bit
     for bit where the BatchNorm sums are ordered (power-of-two group counts), to rounding where they use LDS atomics
     (C = 24)."""
-    import os
     from snn_for_object_detection_amd import _hip
     torch.manual_seed(C + H)
     y = (2.5 * torch.randn(T, B, C, H, W) + 0.3).cuda().requires_grad_()
@@ -199,14 +202,13 @@ def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
     g = torch.randn(T, B, C, H, W).cuda()
     results = []
     for no_buf in (False, True):
-        if no_buf:
-            os.environ["SNN_BWD_NO_BUF"] = "1"
+        HF.SCAN_FLAGS = _hip.SCAN_WIDE_ADDRESSING if no_buf else 0
         try:
             bn = torch.nn.BatchNorm2d(C).cuda().train()
             out, st = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn, addend=x)
             results.append(torch.autograd.grad(out, (y, x, bn.weight, bn.bias), g))
         finally:
-            os.environ.pop("SNN_BWD_NO_BUF", None)
+            HF.SCAN_FLAGS = 0
     ordered = (C // 4) & (C // 4 - 1) == 0
     for a, b in zip(*results):
         assert torch.isfinite(a).all()

@@ -158,3 +158,88 @@ def test_early_targets_and_cached_transposes_match_the_plain_path(S):
     assert conv_w._snn_wt_version == conv_w._version
     _, g_cached = grads(labels)
     assert torch.equal(g_fallback, g_cached)
+
+
+def test_optimizer_state_round_trip_and_torch_interchange(S):
+    """``FlatTrainer.state_dict()`` has torch.optim.Adamax's layout: a torch optimiser loads it and continues exactly
+    like the fused kernel does; a fresh FlatTrainer resumes from it bit for bit (checkpoint / resume)."""
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 3, 2, 32, 48
+    X, labels = synthetic_events(T, B, H, W, p=0.1).cuda(), synthetic_labels(B).cuda()
+
+    def fresh():
+        torch.manual_seed(2)
+        return S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+
+    def one_step(model, trainer):
+        trainer.zero_grad()
+        model.training_step((X, labels)).backward()
+        trainer.step()
+
+    a = fresh()
+    tr_a = FlatTrainer(a, lr=2e-3)
+    for _ in range(2):
+        one_step(a, tr_a)
+    ckpt_model = {k: v.clone() for k, v in a.state_dict().items()}
+    ckpt_opt = tr_a.state_dict()
+    assert set(ckpt_opt) == {"state", "param_groups"} and len(ckpt_opt["state"]) == len(tr_a.params)
+    assert ckpt_opt["state"][0]["exp_avg"].shape == tr_a.params[0].shape
+    one_step(a, tr_a)                                        # the step to reproduce after a resume
+    # resume into a new model + trainer
+    b = fresh()
+    b.load_state_dict(ckpt_model)
+    tr_b = FlatTrainer(b, lr=1e-3)                           # lr comes from the checkpoint
+    tr_b.load_state_dict(ckpt_opt)
+    assert tr_b.step_count == 2 and tr_b.lr == 2e-3
+    one_step(b, tr_b)
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(pa, pb), n
+    # the same state drives torch.optim.Adamax
+    c = fresh()
+    c.load_state_dict(ckpt_model)
+    opt = torch.optim.Adamax([p for p in c.parameters() if p.requires_grad], lr=1e-3)
+    opt.load_state_dict(ckpt_opt)
+    opt.zero_grad()
+    c.training_step((X, labels)).backward()
+    opt.step()
+    for (n, pa), pc in zip(a.named_parameters(), c.parameters()):
+        if pa.requires_grad:
+            assert rel_err(pc, pa) < 1e-5, n
+
+
+def test_parameters_without_gradient_are_left_alone(S):
+    """torch.optim.Adamax skips parameters whose grad is None; the fused step does the same (no decay of their moments,
+    no movement), and a model moved after the trainer was built is refused instead of silently training a copy."""
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    torch.manual_seed(3)
+    blk = BlockGen(2, [Conv(8, 3), Norm(), LIF(), Conv(8, 1)]).cuda().train()
+    extra = BlockGen(8, [Conv(4, 1)]).cuda()                 # never used in the forward pass: no gradient
+    model = torch.nn.ModuleList([blk, extra])
+    tr = FlatTrainer(model, lr=1e-2)
+    x = synthetic_events(3, 2, 12, 16, p=0.3).cuda()
+    w_extra = extra.net[0][0].weight
+    for it in range(2):
+        before = w_extra.detach().clone()
+        tr.zero_grad()
+        if it == 1:                                          # give it non-zero moments first, then starve it
+            w_extra.grad = torch.ones_like(w_extra)
+        out, _ = blk(x)
+        out.square().mean().backward()
+        tr.step()
+        if it == 0:
+            assert torch.equal(w_extra.detach(), before)     # untouched, moments still zero
+            assert float(tr.exp_inf[tr._offsets[-2]:tr._offsets[-1]].abs().max()) == 0.0
+        else:
+            assert not torch.equal(w_extra.detach(), before)
+    moments = tr.exp_avg[tr._offsets[-2]:tr._offsets[-1]].clone()
+    before = w_extra.detach().clone()
+    tr.zero_grad()
+    out, _ = blk(x)
+    out.square().mean().backward()
+    tr.step()                                                # no gradient for `extra` this time
+    assert torch.equal(w_extra.detach(), before) and torch.equal(tr.exp_avg[tr._offsets[-2]:tr._offsets[-1]], moments)
+    assert not torch.equal(blk.net[0][0].weight.detach(), torch.zeros_like(blk.net[0][0].weight))
+    model.float().cpu()
+    with pytest.raises(RuntimeError, match="flat parameter buffer"):
+        tr.step()

@@ -53,16 +53,16 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         _hip.call("snn_weight_transpose", w.data_ptr(), wt.data_ptr(), Cout, k, k, Cin, st)
-        splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k)
+        splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k, 1)
         ws = torch.empty(splitk * w.numel(), device=dev)
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         ops = {
             "fwd": lambda: _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W,
-                                     Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, st),
+                                     Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, 4, st),
             "dgrad": lambda: _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, N,
-                                       H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, st),
+                                       H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, 1, st),
             "wgrad": lambda: _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), N,
-                                       H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 0, ws.data_ptr(), splitk, st),
+                                       H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 0, ws.data_ptr(), splitk, 1, st),
         }
         for name, fn in ops.items():
             if args.only and name != args.only:

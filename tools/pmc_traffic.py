@@ -5,6 +5,9 @@
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py ...
     python tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv out.json
 
+``out.json`` also gets a ``_meta`` entry with the sha256 of the kernel sources the passes ran on: ``bench.py`` reports
+``roofline.traffic`` from the file only while that fingerprint matches the current sources.
+
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE counts
 128-byte requests as 64 bytes for wide coalesced reads, so the read side is DOUBLED; WRITE_SIZE is exact.
 Kernels are grouped by template family (text before '<' / '('), averages are per launch.
@@ -52,8 +55,14 @@ def main():
         wr = 1024.0 * ws / max(wn, 1)
         out[k] = {"launches": max(fn, wn), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                   "hbm_bytes_per_launch": rd + wr}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_fingerprint
+    rows = dict(out)
+    out["_meta"] = {"csrc_sha256": csrc_fingerprint(), "units": "bytes per launch; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024",
+                    "passes": [os.path.basename(os.path.dirname(a)) for a in sys.argv[1:3]]}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:16]:
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:16]:
         print(f"{k:52s} n={v['launches']:5d}  read {v['read_bytes_per_launch'] / 1e6:9.1f} MB  "
               f"write {v['write_bytes_per_launch'] / 1e6:9.1f} MB per launch")
 

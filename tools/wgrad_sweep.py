@@ -23,11 +23,11 @@ RESULTS = []
 
 
 def run(label):
-    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k)
+    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k, 1)
     ws = torch.empty(splitk * dw.numel(), device=dev)
     def call():
         _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), N, H, W, Cin, Ho, Wo, Cout,
-                  k, k, s, pad, 0, ws.data_ptr(), splitk, st)
+                  k, k, s, pad, 0, ws.data_ptr(), splitk, 1, st)
     for _ in range(2):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
