@@ -109,8 +109,10 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
  * dgrad: dx[n,hi,wi,ci]  = sum_{kh,kw,co} dy[n,(hi+pad-kh)/s,(wi+pad-kw)/s,co] * wt[ci,kh,kw,co]
  *        (terms with a non-integral or out-of-range source pixel are 0; wt from snn_weight_transpose)
  * wgrad: dw[co,kh,kw,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n, ho*s-pad+kh, wo*s-pad+kw, ci]
- *        split over `splitk` pixel ranges into `workspace` ([splitk][Cout*KH*KW*Cin] floats),
- *        then reduced in fixed order (bitwise reproducible).
+ *        partial sums over pixel ranges go to `workspace` ([splitk][Cout*KH*KW*Cin] floats, splitk from
+ *        snn_conv2d_wgrad_splitk), then reduced in fixed order (bitwise reproducible).  3x3 / pad 1 / stride 1|2
+ *        layers with Cin, Cout multiples of 32 take the halo-resident kernel (csrc/wgrad_halo.hip), the rest the
+ *        implicit-GEMM kernel.
  * fwd / dgrad `addend` (may be NULL): a tensor of the result's shape with pixel stride ld_addend that is added
  *   in the epilogue (result = conv + addend); passing the destination itself accumulates in place.  This
  *   fuses the gradient sum of a tensor consumed by several branches (generator.py:181-187) into the dgrad.
@@ -130,9 +132,10 @@ int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, int accumulate,
                      float* workspace, int splitk, int precision, void* stream);
-/* number of pixel splits snn_conv2d_wgrad wants for this shape and precision (workspace = splitk*Cout*KH*KW*Cin
- * floats); host-only, callable without a device */
-int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int precision);
+/* number of workspace slabs snn_conv2d_wgrad wants for this shape and precision (workspace = splitk*Cout*KH*KW*Cin
+ * floats); same geometry arguments as snn_conv2d_wgrad; host-only, callable without a device */
+int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                            int stride, int pad, int precision);
 
 /* ---------------------------------------------------------------- batch-norm statistics
  * Train-mode nn.BatchNorm2d (layer_gen.py:211-214) applied per TIMESTEP: for every (t,c)

@@ -43,7 +43,7 @@ SIGNATURES = {
                                  _I, _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P]),
-    "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I]),
+    "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
     "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_bn_stats_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),

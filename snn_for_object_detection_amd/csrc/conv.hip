@@ -1201,6 +1201,34 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
     if (kg == 0 && e < n) dw[e] = accumulate ? dw[e] + s : s;
 }
 
+// The same ordered reduction, 16 bytes per lane and whole 4 KiB runs per block (the kernel above reads 16 ... 64 bytes
+// per slab row and block: 0.8 TB/s on the 2 000-slab workspaces of the narrow layers).  dst[g][e] = sum of rows
+// [g * per, (g + 1) * per) of src in row order (+ dst when accumulate); a first pass reduces groups of rows IN PLACE
+// (into the first row of each group - every thread only overwrites positions it has read itself), a second pass adds
+// the group heads.
+__global__ __launch_bounds__(kThreads) void k_wgrad_reduce4(const float* __restrict__ src, int64_t n, int rows, int per,
+                                                            int64_t row_stride, float* __restrict__ dst,
+                                                            int64_t dst_group_stride, int accumulate) {
+    const int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (e >= n) return;
+    const int g = blockIdx.y;
+    const int r0 = g * per;
+    const int r1 = r0 + per < rows ? r0 + per : rows;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)r * row_stride + e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 1) * row_stride + e);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 2) * row_stride + e);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 3) * row_stride + e);
+        s = (((s + a) + b) + c) + d;
+    }
+    for (; r < r1; ++r) s = s + *reinterpret_cast<const f32x4*>(src + (int64_t)r * row_stride + e);
+    float* out = dst + (int64_t)g * dst_group_stride + e;
+    if (accumulate) s = *reinterpret_cast<const f32x4*>(out) + s;
+    *reinterpret_cast<f32x4*>(out) = s;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <bool DGRAD, int SPLIT>
@@ -1910,9 +1938,14 @@ static WgradTile wgrad_tile(int Cout, int Ktot, bool split, int64_t M) {
 }
 }  // namespace
 
-extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int precision) {
+extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                       int stride, int pad, int precision) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
     const int bwd_split = precision == SNN_PREC_FP32 ? 0 : 1;
+    if (bwd_split) {  // 3x3 layers with whole 32-channel tiles: the halo-resident kernel (wgrad_halo.hip)
+        const SnnWgradHaloPlan hp = snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad);
+        if (hp.ok) return hp.slabs;
+    }
     const int64_t M = N * Ho * (int64_t)Wo;
     const int64_t Ktot = (int64_t)KH * KW * Cin;
     if (first_layer_shape(Cin, Cout, KH, KW)) return first_layer_blocks(N * Ho);  // one slab per block
@@ -1944,7 +1977,26 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int Ho, int Wo, int Cin, int C
 }
 
 // dw (+)= sum over the splitk workspace slabs, fixed order
-static int wgrad_reduce_slabs(const float* workspace, float* dw, int64_t n, int splitk, int accumulate, hipStream_t st) {
+static int wgrad_reduce_slabs(float* workspace, float* dw, int64_t n, int splitk, int accumulate, hipStream_t st) {
+    if (n % 4 == 0 && aligned16(workspace) && aligned16(dw) && splitk > 8) {
+        const int64_t nb = snn_ceil_div(n / 4, kThreads);
+        int64_t groups = snn_ceil_div(4 * snn_num_cu(), nb);   // ~4 blocks per CU in the first pass
+        if (groups > splitk / 4) groups = splitk / 4;          // at least 4 rows per group
+        if (groups < 1) groups = 1;
+        const int per = (int)snn_ceil_div(splitk, groups);
+        groups = snn_ceil_div(splitk, per);
+        if (groups > 1) {
+            hipLaunchKernelGGL(k_wgrad_reduce4, dim3((unsigned)nb, (unsigned)groups), dim3(kThreads), 0, st, workspace,
+                               n, splitk, per, n, workspace, (int64_t)per * n, 0);
+            hipLaunchKernelGGL(k_wgrad_reduce4, dim3((unsigned)nb, 1), dim3(kThreads), 0, st, workspace, n,
+                               (int)groups, (int)groups, (int64_t)per * n, dw, 0, accumulate);
+        } else {
+            hipLaunchKernelGGL(k_wgrad_reduce4, dim3((unsigned)nb, 1), dim3(kThreads), 0, st, workspace, n, splitk,
+                               splitk, n, dw, 0, accumulate);
+        }
+        SNN_CHECK_LAUNCH("snn_conv2d_wgrad_reduce");
+        return 0;
+    }
 #define SNN_REDUCE_LAUNCH(KG_)                                                                                  \
     hipLaunchKernelGGL((k_wgrad_reduce<KG_>), dim3((unsigned)snn_ceil_div(n, kThreads / KG_)), dim3(kThreads), 0, \
                        st, workspace, dw, n, splitk, accumulate)
@@ -1982,6 +2034,20 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
                            (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
         return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
+    }
+    if (bwd_split) {
+        const SnnWgradHaloPlan hp = snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad);
+        if (hp.ok) {
+            SNN_REQUIRE(splitk == hp.slabs, "snn_conv2d_wgrad: splitk %d, expected %d (snn_conv2d_wgrad_splitk)", splitk,
+                        hp.slabs);
+            const int rc = snn_wgrad_halo_launch(hp, x, ldx, dy, lddy, workspace, N, H, W, Cin, Ho, Wo, Cout, stride,
+                                                 (hipStream_t)stream);
+            if (rc == 0)
+                return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, hp.slabs, accumulate,
+                                          (hipStream_t)stream);
+            if (rc > 0) return rc;
+            // rc < 0: buffers this kernel cannot address (unaligned / > 2 GiB per image): the implicit-GEMM kernel
+        }
     }
     const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
                      aligned16(dy);

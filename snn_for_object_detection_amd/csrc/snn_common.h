@@ -53,5 +53,22 @@ static inline const char* snn_tuning_env(const char* name) { return getenv(name)
 static inline const char* snn_tuning_env(const char*) { return nullptr; }
 #endif
 
+// ---- halo-resident 3x3 weight gradient (wgrad_halo.hip), used by snn_conv2d_wgrad / snn_conv2d_wgrad_splitk
+struct SnnWgradHaloPlan {
+    int ok;                      // 0: shape not covered (the implicit-GEMM weight gradient takes it)
+    int R, CW, npr, npc, nks;    // patch rows / columns, patches per image column / row, K16 steps per patch
+    int HR, HC, HWD, HWD2;       // halo rows / columns, LDS row pitch in pixels, parity offset (stride 2)
+    int wco, wk;                 // waves over output channels / over the K-steps of a patch
+    int tiles_co, tiles_ci, splits, pps, patches;
+    int slabs;                   // workspace slabs the launch writes (= splits: the K-sharing waves add up in LDS)
+};
+SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                     int stride, int pad);
+// 0 ok, 2 launch error, -1 buffers not addressable by this kernel (caller falls back; the plan must not have been
+// used to size the workspace in that case - the caller checks the same conditions before planning)
+int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
+                          float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
+                          hipStream_t st);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -498,7 +498,7 @@ class _Conv2d(Function):
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
             dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec)
         if ctx.needs_input_grad[1]:
-            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, Ho, Wo, Cin, Cout, KH, KW, ctx.prec)
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
             if ctx.slot is not None and USE_WGRAD_STREAM:
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
@@ -573,7 +573,7 @@ class _ComposedConv1x1(Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             slot1, slot2 = ctx.slots
             slotted = slot1 is not None and slot2 is not None
-            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, C2, 1, 1, ctx.prec)
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, H, W, C2, 1, 1, 1, 0, ctx.prec)
             side_ok = slotted and USE_WGRAD_STREAM
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main

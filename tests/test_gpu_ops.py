@@ -66,6 +66,54 @@ def test_conv2d_fwd_bwd(HF, T, B, Cin, H, W, Cout, k, s):
     assert rel_err(wd.grad, wr.grad) < 1e-5
 
 
+HALO_WGRAD_CASES = [
+    # N, Cin, H, W, Cout, stride      (3x3, pad 1: the halo-resident weight gradient, csrc/wgrad_halo.hip, takes the
+    # layers with at least 150 000 output pixels; the smaller cases below cover the implicit-GEMM path on the same shapes)
+    (140, 128, 30, 38, 128, 1),  # four waves over output channels, four input-channel tiles, ragged patch columns
+    (90, 32, 40, 44, 32, 1),     # K-steps of a patch split over the four waves (32 output channels)
+    (96, 64, 21, 76, 64, 1),     # two waves over channels x two over K; partial last patch row
+    (330, 64, 37, 52, 128, 2),   # stride 2, odd height: parity-de-interleaved halo columns
+    (540, 128, 30, 38, 256, 2),  # stride 2, two output-channel tiles
+    (1900, 256, 15, 19, 256, 2), # stride 2, odd sizes, eight input-channel tiles
+    (1900, 128, 8, 10, 128, 1),  # one patch per image
+    (2100, 32, 9, 8, 64, 1),     # images narrower than most patches
+    (6, 128, 30, 38, 128, 1), (3, 64, 37, 52, 128, 2),   # below the size threshold: implicit-GEMM kernel
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,s", HALO_WGRAD_CASES)
+def test_wgrad_halo_kernel_against_fp64(HF, hip_lib, N, Cin, H, W, Cout, s):
+    """snn_conv2d_wgrad through the C ABI on the shapes that take the halo-resident kernel: against an fp64
+    convolution backward, with x and dy being channel slices of wider buffers (pixel strides > channel counts),
+    bitwise reproducible, and `accumulate` adding to the destination."""
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(N * 100 + Cin + Cout + s)
+    st = torch.cuda.current_stream().cuda_stream
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    xw = torch.randn(N, H, W, Cin + 32, device="cuda")
+    dyw = torch.randn(N, Ho, Wo, Cout + 64, device="cuda")
+    x, dy = xw[..., 32:], dyw[..., 32:32 + Cout]             # 16-byte aligned channel slices
+    prec = _hip.PREC_BF16X3
+    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, Ho, Wo, Cout, 3, 3, s, 1, prec)
+    ws = torch.empty(splitk, Cout * 9 * Cin, device="cuda")
+    outs = []
+    for _ in range(2):
+        ws.fill_(float("nan"))                                # every slab element must be written
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+        _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin + 32, dy.data_ptr(), Cout + 64, dw.data_ptr(), N, H, W, Cin, Ho,
+                  Wo, Cout, 3, 3, s, 1, 0, ws.data_ptr(), splitk, prec, st)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    yref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wref, stride=s, padding=1)
+    yref.backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = wref.grad.permute(0, 2, 3, 1)                       # OHWI like dw
+    assert rel_err(outs[0], ref) < 1e-5
+    _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin + 32, dy.data_ptr(), Cout + 64, outs[0].data_ptr(), N, H, W, Cin, Ho,
+              Wo, Cout, 3, 3, s, 1, 1, ws.data_ptr(), splitk, prec, st)
+    assert rel_err(outs[0], 2.0 * ref) < 1e-5
+
+
 def test_conv2d_single_step_and_determinism(HF):
     torch.manual_seed(3)
     x = torch.randn(2, 16, 10, 12).cuda().requires_grad_()

@@ -67,7 +67,7 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
         assert hasattr(raw, name), name
     assert hip_lib.snn_abi_version() == _hip.ABI_VERSION
     # shape planning helpers are host-only and callable without a GPU
-    assert hip_lib.snn_conv2d_wgrad_splitk(160, 120, 152, 32, 32, 3, 3, _hip.PREC_BF16X3) >= 1
+    assert hip_lib.snn_conv2d_wgrad_splitk(160, 120, 152, 32, 120, 152, 32, 3, 3, 1, 1, _hip.PREC_BF16X3) >= 1
     assert hip_lib.snn_bn_stats_partial_size(32, 5 * 120 * 152, 64) > 0
     assert hip_lib.snn_affine_neuron_bwd_sums_size(32, 5 * 120 * 152, 64) > 0
 

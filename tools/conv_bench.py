@@ -53,7 +53,7 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         _hip.call("snn_weight_transpose", w.data_ptr(), wt.data_ptr(), Cout, k, k, Cin, st)
-        splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k, 1)
+        splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 1)
         ws = torch.empty(splitk * w.numel(), device=dev)
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         ops = {

@@ -19,7 +19,7 @@ wt = torch.randn(Cin, k, k, Cout, device=dev) * 0.05
 y = torch.empty(N, Ho, Wo, Cout, device=dev)
 dy = torch.randn(N, Ho, Wo, Cout, device=dev)
 dx, dw = torch.empty_like(x), torch.empty_like(w)
-splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k, 1)
+splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 1)
 ws = torch.empty(splitk * w.numel(), device=dev)
 for _ in range(3):
     if op == "fwd":

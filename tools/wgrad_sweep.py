@@ -23,7 +23,7 @@ RESULTS = []
 
 
 def run(label):
-    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, Ho, Wo, Cin, Cout, k, k, 1)
+    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 1)
     ws = torch.empty(splitk * dw.numel(), device=dev)
     def call():
         _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), N, H, W, Cin, Ho, Wo, Cout,
