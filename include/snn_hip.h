@@ -251,6 +251,13 @@ int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst
 int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream);
 int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n, void* stream);
 
+/* C (+)= op(A) x op(B), row-major fp32, op = transpose when the flag is set: A is [M][K] ([K][M] transposed), B is [K][N]
+ * ([N][K] transposed), C is [M][N]; every element is an fmaf chain in k order.  For weight-sized matrices: two 1x1
+ * convolutions with nothing between them (the C2f entry, models/tiny_yolo.py:76-82) are composed into one, and
+ * their weight gradients are products of the composed gradient with the other factor. */
+int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                   int64_t ldc, int M, int N, int K, int accumulate, void* stream);
+
 /* ConvLSTM cell (conv_lstm.py:51-78), pointwise part after the 1x1 gate convolution.  gates is dense
  * [M][4C] = (input, forget, output, candidate); c_prev NULL = zero state.
  *   c = sigmoid(f)*c_prev + sigmoid(i)*tanh(g);  h = sigmoid(o)*tanh(c) */
@@ -293,6 +300,29 @@ int snn_detect_decode(const float* cls_prob, const float* offsets, const float* 
  * only while IoU <= iou_threshold against every kept box (so a NaN IoU suppresses, as utils/box.py:95-97 does). */
 int snn_nms_sorted(const float* boxes, const int* order, const int* seg, int num_classes, float iou_threshold,
                    int* kept, int* nkept, unsigned char* kept_flag, int* kept_rank, void* stream);
+
+/* ---------------------------------------------------------------- training targets and loss
+ * snn_roi_assign: RoI.__call__ (utils/roi.py:18-109) for a whole batch, one block per sample.  anchors [A][4] corner
+ * boxes, labels [B][N][5] rows (class, x1, y1, x2, y2) with -1 padding rows (which, as upstream, still claim an anchor
+ * in the greedy phase).  An anchor takes the ground truth of highest IoU when that IoU >= iou_threshold, then every
+ * label row claims the globally best remaining anchor (first maximum on ties).  Outputs: bbox_offset [B][A][4] =
+ * offset_boxes(anchor, assigned box) * mask (utils/box.py:62-69), bbox_mask [B][A][4] (0 / 1), class_labels [B][A]
+ * int64 (0 = background, label + 1 otherwise).  workspace: snn_roi_workspace_size(B, A, N) bytes. */
+size_t snn_roi_workspace_size(int B, int A, int N);
+int snn_roi_assign(const float* anchors, const float* labels, int B, int A, int N, float iou_threshold,
+                   void* workspace, float* bbox_offset, float* bbox_mask, int64_t* class_labels, void* stream);
+/* SODa._loss (models/soda.py:259-281) over rows = B*A anchors with K = classes + 1 logits each:
+ *   loss = loss_ratio * mean(CE[label > 0]) + (1 - loss_ratio) * mean(CE[label == 0]) + mean |bbox*mask - offset*mask|
+ * fwd writes the scalar loss and stats[5] = {sum CE pos, #pos, sum CE neg, #neg, sum L1} (fp64, kept for bwd);
+ * bwd writes d loss / d logits [rows][K] and d loss / d bbox [rows][4], scaled by the device scalar *g_loss.
+ * workspace: snn_det_loss_workspace_size(rows) bytes. */
+size_t snn_det_loss_workspace_size(int64_t rows);
+int snn_det_loss_fwd(const float* cls_logits, const float* bbox_preds, const float* bbox_offset, const float* bbox_mask,
+                     const int64_t* class_labels, int64_t rows, int K, float loss_ratio, void* workspace, double* stats,
+                     float* loss, void* stream);
+int snn_det_loss_bwd(const float* cls_logits, const float* bbox_preds, const float* bbox_offset, const float* bbox_mask,
+                     const int64_t* class_labels, int64_t rows, int K, float loss_ratio, const double* stats,
+                     const float* g_loss, float* g_logits, float* g_bbox, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_NAME = "libsnn_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ("elementwise.hip", "neuron.hip", "conv.hip", "wgrad_halo.hip", "detect.hip")
+SOURCES = ("elementwise.hip", "neuron.hip", "conv.hip", "wgrad_halo.hip", "detect.hip", "targets.hip")
 ARCH = "gfx950"
 # -ffp-contract=off: the pointwise kernels must round like the reference's unfused torch ops.
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall",

@@ -327,6 +327,62 @@ __global__ void k_events(const int32_t* __restrict__ tb, const int32_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------ small GEMM
+// C (+)= op(A) x op(B) for weight-sized matrices (<= a few hundred per side): the three products of a composed pair of
+// 1x1 convolutions (functional._ComposedConv1x1: w2 w1, G w1^T, w2^T G).  32 x 32 tile per block, 2 x 2 per thread;
+// K goes through LDS in chunks of 128 whose loads are all in flight at once (these launches are latency-, not
+// throughput-bound: one memory round trip per chunk instead of one per 16 k); every element is an fp32 fmaf chain in
+// k order (same arithmetic as the fp32 MFMA).
+constexpr int GEMM_KC = 128;
+template <bool TA, bool TB>
+__global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                         int accumulate) {
+    __shared__ float As[GEMM_KC][33], Bs[GEMM_KC][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
+        float ra[GEMM_KC * 32 / kThreads], rb[GEMM_KC * 32 / kThreads];
+#pragma unroll
+        for (int r = 0; r < GEMM_KC * 32 / kThreads; ++r) {   // lanes run along the contiguous dimension of each operand
+            const int idx = threadIdx.x + r * kThreads;
+            const int ak = TA ? idx >> 5 : idx & (GEMM_KC - 1), am = TA ? idx & 31 : idx / GEMM_KC;
+            const int bk = TB ? idx & (GEMM_KC - 1) : idx >> 5, bn = TB ? idx / GEMM_KC : idx & 31;
+            const int m = m0 + am, n = n0 + bn;
+            ra[r] = (m < M && k0 + ak < K) ? (TA ? A[(int64_t)(k0 + ak) * lda + m] : A[(int64_t)m * lda + k0 + ak]) : 0.f;
+            rb[r] = (n < N && k0 + bk < K) ? (TB ? B[(int64_t)n * ldb + k0 + bk] : B[(int64_t)(k0 + bk) * ldb + n]) : 0.f;
+        }
+        __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+        for (int r = 0; r < GEMM_KC * 32 / kThreads; ++r) {
+            const int idx = threadIdx.x + r * kThreads;
+            const int ak = TA ? idx >> 5 : idx & (GEMM_KC - 1), am = TA ? idx & 31 : idx / GEMM_KC;
+            const int bk = TB ? idx & (GEMM_KC - 1) : idx >> 5, bn = TB ? idx / GEMM_KC : idx & 31;
+            As[ak][am] = ra[r];
+            Bs[bk][bn] = rb[r];
+        }
+        __syncthreads();
+        const int kend = K - k0 < GEMM_KC ? K - k0 : GEMM_KC;
+        for (int kk = 0; kk < kend; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = fmaf(As[kk][ty + 16 * i], Bs[kk][tx + 16 * j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) {
+                float* c = C + (int64_t)m * ldc + n;
+                *c = accumulate ? *c + acc[i][j] : acc[i][j];
+            }
+        }
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------- C ABI
@@ -426,6 +482,21 @@ extern "C" int snn_act_bwd(int act, const float* x, const float* y, const float*
     SNN_REQUIRE(x && y && gy && gx && n > 0 && act >= SNN_ACT_RELU && act <= SNN_ACT_TANH, "snn_act_bwd: bad arguments");
     hipLaunchKernelGGL(k_act_bwd, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, act, x, y, gy, gx, n);
     SNN_CHECK_LAUNCH("snn_act_bwd");
+    return 0;
+}
+
+extern "C" int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                              int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
+    SNN_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "snn_small_gemm: bad arguments");
+    SNN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "snn_small_gemm: leading dimension "
+                "smaller than the row length");
+    dim3 grid((unsigned)snn_ceil_div(N, 32), (unsigned)snn_ceil_div(M, 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (transA && transB) hipLaunchKernelGGL((k_small_gemm<true, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
+    else if (transA) hipLaunchKernelGGL((k_small_gemm<true, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
+    else if (transB) hipLaunchKernelGGL((k_small_gemm<false, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
+    else hipLaunchKernelGGL((k_small_gemm<false, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
+    SNN_CHECK_LAUNCH("snn_small_gemm");
     return 0;
 }
 

@@ -525,6 +525,14 @@ class _Conv2d(Function):
         return dx, dw, None, None, None, None, None, None
 
 
+def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int) -> None:
+    """``c (+)= op(a) @ op(b)`` on dense row-major fp32 matrices (``snn_small_gemm``, current stream)."""
+    m, n = c.shape
+    k = a.shape[0] if trans_a else a.shape[1]
+    _hip.call("snn_small_gemm", a.data_ptr(), a.shape[1], int(trans_a), b.data_ptr(), b.shape[1], int(trans_b),
+              c.data_ptr(), n, m, n, k, int(accumulate), _stream())
+
+
 class _ComposedConv1x1(Function):
     """``conv1x1(conv1x1(x, w1), w2)`` without the intermediate tensor (no Norm / neuron between the two: the C2f
     entry ``Conv(c, 1)`` followed by the branch-opening ``Conv(c/2, 1)`` of ``models/tiny_yolo.py:76-82``).
@@ -546,7 +554,10 @@ class _ComposedConv1x1(Function):
         x = _raw_to_cl(x)
         w1m = w1.detach().reshape(C1, Cin)
         w2m = w2.detach().reshape(C2, C1)
-        wc = torch.mm(w2m, w1m).contiguous()                  # [C2, Cin] = OHWI of a 1x1 kernel
+        if not (w1m.is_contiguous() and w2m.is_contiguous()):
+            w1m, w2m = w1m.contiguous(), w2m.contiguous()
+        wc = torch.empty((C2, Cin), device=x.device, dtype=_F32)   # w2 w1: [C2, Cin] = OHWI of a 1x1 kernel
+        _small_gemm(w2m, False, w1m, False, wc, 0)
         y = _out_tensor(dest, T, B, C2, H, W, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
                   Cin, H, W, C2, 1, 1, 1, 0, None, 0, fwd_prec, _stream())
@@ -568,7 +579,8 @@ class _ComposedConv1x1(Function):
         st = _stream()
         dx = dw1 = dw2 = None
         if ctx.needs_input_grad[0]:
-            wct = wc.t().contiguous()                         # [Cin, C2] = transposed 1x1 weight
+            wct = torch.empty((Cin, C2), device=x.device, dtype=_F32)   # (w2 w1)^T = w1^T w2^T: transposed 1x1 weight
+            _small_gemm(w1m, True, w2m, True, wct, 0)
             dx = _dgrad_accumulate(ctx.acc, gy, ldg, wct, x, ctx.geom, st, ctx.prec)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             slot1, slot2 = ctx.slots
@@ -585,15 +597,16 @@ class _ComposedConv1x1(Function):
                 G = torch.empty((C2, Cin), device=x.device, dtype=_F32)
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
                           W, C2, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, ctx.prec, stream.cuda_stream)
-                g2 = torch.mm(G, w1m.t())                     # [C2, C1]
-                g1 = torch.mm(w2m.t(), G)                     # [C1, Cin]
+                # dw2 = G w1^T [C2, C1], dw1 = w2^T G [C1, Cin]: straight into the flat gradient slots when there are any
                 if slotted:
-                    for slot, g in ((slot2, g2), (slot1, g1)):
-                        view = slot.buf.view(g.shape)
-                        if slot.claim():
-                            view.add_(g)
-                        else:
-                            view.copy_(g)
+                    g2, g1 = slot2.buf.view(C2, C1), slot1.buf.view(C1, Cin)
+                    acc2, acc1 = slot2.claim(), slot1.claim()
+                else:
+                    g2 = torch.empty((C2, C1), device=x.device, dtype=_F32)
+                    g1 = torch.empty((C1, Cin), device=x.device, dtype=_F32)
+                    acc2 = acc1 = 0
+                _small_gemm(G, False, w1m, True, g2, acc2)
+                _small_gemm(w2m, True, G, False, g1, acc1)
             if side_ok:
                 _side_hold(stream, x, gy)
             if not slotted:
@@ -1246,6 +1259,50 @@ class _StackTime(Function):
 
 def stack_time(xs: List[torch.Tensor]) -> torch.Tensor:
     return _StackTime.apply(*xs)
+
+
+# ------------------------------------------------------------------------------------------- detection loss
+class _DetectionLoss(Function):
+    """``loss_ratio * mean(CE[pos]) + (1 - loss_ratio) * mean(CE[neg]) + mean(L1(bbox*mask, offset*mask))``
+    (models/soda.py:259-281) and its gradient: two kernel launches forward, one backward, no host round trip."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, bbox_preds, bbox_offset, bbox_mask, class_labels, loss_ratio: float):
+        _require_device(cls_preds, "loss: class predictions")
+        _require_device(bbox_preds, "loss: box predictions")
+        K = cls_preds.shape[-1]
+        logits, boxes = cls_preds.detach().contiguous(), bbox_preds.detach().contiguous()
+        off, msk = bbox_offset.contiguous(), bbox_mask.contiguous()
+        lab = class_labels.contiguous()
+        rows = lab.numel()
+        if logits.numel() != rows * K or boxes.numel() != rows * 4 or off.numel() != rows * 4 or lab.dtype != torch.int64:
+            raise RuntimeError("detection loss: predictions and targets differ in shape")
+        dev = logits.device
+        ws = torch.empty(_hip.query("snn_det_loss_workspace_size", rows), device=dev, dtype=torch.uint8)
+        stats = torch.empty(5, device=dev, dtype=torch.float64)
+        loss = torch.empty((), device=dev, dtype=_F32)
+        _hip.call("snn_det_loss_fwd", logits.data_ptr(), boxes.data_ptr(), off.data_ptr(), msk.data_ptr(),
+                  lab.data_ptr(), rows, K, float(loss_ratio), ws.data_ptr(), stats.data_ptr(), loss.data_ptr(), _stream())
+        ctx.save_for_backward(logits, boxes, off, msk, lab, stats)
+        ctx.loss_ratio = float(loss_ratio)
+        ctx.shapes = (cls_preds.shape, bbox_preds.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, boxes, off, msk, lab, stats = ctx.saved_tensors
+        rows, K = lab.numel(), logits.shape[-1]
+        g = g.detach().to(_F32).contiguous()
+        g_logits, g_boxes = torch.empty_like(logits), torch.empty_like(boxes)
+        _hip.call("snn_det_loss_bwd", logits.data_ptr(), boxes.data_ptr(), off.data_ptr(), msk.data_ptr(),
+                  lab.data_ptr(), rows, K, ctx.loss_ratio, stats.data_ptr(), g.data_ptr(), g_logits.data_ptr(),
+                  g_boxes.data_ptr(), _stream())
+        return g_logits.view(ctx.shapes[0]), g_boxes.view(ctx.shapes[1]), None, None, None, None
+
+
+def detection_loss(cls_preds: torch.Tensor, bbox_preds: torch.Tensor, bbox_offset: torch.Tensor,
+                   bbox_mask: torch.Tensor, class_labels: torch.Tensor, loss_ratio: float) -> torch.Tensor:
+    return _DetectionLoss.apply(cls_preds, bbox_preds, bbox_offset, bbox_mask, class_labels, loss_ratio)
 
 
 # ------------------------------------------------------------------------------------------- events

@@ -1,9 +1,9 @@
 """Anchor <-> ground-truth assignment (mirror of the reference's ``utils/roi.py``).
 
 Same arithmetic and the same results as ``utils/roi.py:18-109`` (pinned bit-exactly by
-``tests/golden/detect_roi.npz``), re-expressed without host synchronisation: no ``nonzero`` / boolean
-indexing / ``len()`` of device tensors, so on the device the target computation never stalls the launch
-queue of the training step.
+``tests/golden/detect_roi.npz``).  Device tensors take ONE HIP kernel launch for the whole batch
+(``snn_roi_assign``, ``csrc/targets.hip``: one block per sample, the greedy per-ground-truth phase included); the
+tensor form below is the host path the fixtures pin, written without ``nonzero`` / boolean indexing.
 """
 
 import torch
@@ -23,6 +23,8 @@ class RoI:
         self.iou_threshold = iou_threshold
 
     def __call__(self, anchors: torch.Tensor, labels: torch.Tensor):
+        if anchors.is_cuda:
+            return self._device(anchors, labels)
         offsets, masks, classes = [], [], []
         for label in labels:
             amap = self._assign_anchor_to_box(label[:, 1:], anchors)
@@ -35,6 +37,22 @@ class RoI:
             masks.append(bbox_mask)
             classes.append(class_labels)
         return torch.stack(offsets), torch.stack(masks), torch.stack(classes)
+
+    def _device(self, anchors: torch.Tensor, labels: torch.Tensor):
+        from . import _hip
+        anchors = anchors.detach().contiguous().float()
+        labels = labels.detach().to(anchors.device).contiguous().float()
+        B, N, _ = labels.shape
+        A = anchors.shape[0]
+        dev = anchors.device
+        ws = torch.empty(_hip.query("snn_roi_workspace_size", B, A, N), device=dev, dtype=torch.uint8)
+        offset = torch.empty((B, A, 4), device=dev, dtype=torch.float32)
+        mask = torch.empty((B, A, 4), device=dev, dtype=torch.float32)
+        cls = torch.empty((B, A), device=dev, dtype=torch.int64)
+        _hip.call("snn_roi_assign", anchors.data_ptr(), labels.data_ptr(), B, A, N, float(self.iou_threshold),
+                  ws.data_ptr(), offset.data_ptr(), mask.data_ptr(), cls.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        return offset, mask, cls
 
     def _assign_anchor_to_box(self, ground_truth: torch.Tensor, anchors: torch.Tensor) -> torch.Tensor:
         num_gt = ground_truth.shape[0]

@@ -53,9 +53,6 @@ class SODa(nn.Module):
         self.roi_blk = RoI(self.hparams.iou_threshold)
         self.cls_loss = nn.CrossEntropyLoss(reduction="none")
         self.box_loss = nn.L1Loss(reduction="none")
-        # anchors of the last forward, keyed by the frame size: lets the next step compute its targets EARLY
-        self._anchor_cache = {}
-        self._target_streams = {}
 
     # ------------------------------------------------------------------ description hooks
     def backbone_cfgs(self) -> ListGen:
@@ -98,32 +95,10 @@ class SODa(nn.Module):
         return (anchors, cls_preds, bbox_preds), state
 
     # ------------------------------------------------------------------ steps
-    def _early_targets(self, X: torch.Tensor, labels: torch.Tensor):
-        """Anchor targets depend on the labels and the (frame-size dependent, cached) anchors only - not on the
-        forward pass.  From the second step on they are computed on the side stream WHILE the forward pass runs:
-        the ~300 tiny launches of the per-sample assignment (`utils/roi.py` loops over the batch) leave the
-        critical path between forward and backward (2.8 ms of 36 per step before)."""
-        key = (tuple(X.shape[-2:]), X.device)
-        anchors = self._anchor_cache.get(key)
-        if anchors is None or not X.is_cuda:
-            return None
-        main = torch.cuda.current_stream()
-        side = self._target_streams.get(X.device)
-        if side is None:  # a stream of its own: the weight-gradient side stream is busy with the previous backward
-            side = self._target_streams[X.device] = torch.cuda.Stream(device=X.device)
-        side.wait_stream(main)  # the labels are ready
-        with torch.cuda.stream(side):
-            targets = self.roi_blk(anchors, labels)
-            done = torch.cuda.Event()
-            done.record(side)
-        return anchors, targets, done
-
     def _step(self, batch: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
         X, labels = batch[0][self._rand_start_time():], batch[1]
-        early = self._early_targets(X, labels)
         preds = self.forward(X)
-        self._anchor_cache = {(tuple(X.shape[-2:]), X.device): preds[0].detach()}
-        return self._loss(preds, labels, early)
+        return self._loss(preds, labels)
 
     def training_step(self, batch: Tuple[torch.Tensor, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
         loss = self._step(batch)
@@ -158,34 +133,21 @@ class SODa(nn.Module):
             return 0
         return int(torch.randint(0, self.hparams.time_window, (1,)).item())
 
-    def _loss(self, preds: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], labels: torch.Tensor,
-              early=None) -> torch.Tensor:
+    def _loss(self, preds: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], labels: torch.Tensor) -> torch.Tensor:
         # soda.py:259-281
         anchors, cls_preds, bbox_preds = preds
-        targets = None
-        if early is not None:
-            # ALWAYS join the target stream, also when its result is dropped: it read `labels`, which the main
-            # stream may free or overwrite from here on
-            early_anchors, targets, done = early
-            main = torch.cuda.current_stream()
-            main.wait_event(done)
-            for t in targets:
-                t.record_stream(main)  # allocated on the side stream, consumed (or released) here
-            if early_anchors.shape != anchors.shape:
-                targets = None
-        if targets is None:
-            targets = self.roi_blk(anchors, labels)
-        bbox_offset, bbox_mask, class_labels = targets
+        bbox_offset, bbox_mask, class_labels = self.roi_blk(anchors, labels)
+        if cls_preds.is_cuda:
+            # one launch for the anchor targets (RoI above), two for the loss, one for its gradient (csrc/targets.hip)
+            from . import functional as HF
+            return HF.detection_loss(cls_preds, bbox_preds, bbox_offset, bbox_mask, class_labels,
+                                     self.hparams.loss_ratio)
         _, _, num_classes = cls_preds.shape
         cls = self.cls_loss.forward(cls_preds.reshape(-1, num_classes), class_labels.reshape(-1))
         bbox = self.box_loss.forward(bbox_preds * bbox_mask, bbox_offset * bbox_mask)
-        # masked means without boolean indexing (= cls[mask].mean(), cls[~mask].mean(); no host sync).  torch.where,
-        # not a product with the mask: a non-finite CE value at an anchor OUTSIDE a set must not reach that set's
-        # mean (0 * inf = NaN), exactly as the reference's boolean indexing ignores it
         mask = class_labels.reshape(-1) > 0
-        zero = torch.zeros_like(cls)
-        gt_loss = torch.where(mask, cls, zero).sum() / mask.sum()
-        background_loss = torch.where(mask, zero, cls).sum() / (~mask).sum()
+        gt_loss = cls[mask].mean()
+        background_loss = cls[~mask].mean()
         return (gt_loss * self.hparams.loss_ratio + background_loss * (1 - self.hparams.loss_ratio) + bbox.mean())
 
     def spike_taps(self):

@@ -1,7 +1,11 @@
 """Device detection decode: HIP decode + greedy NMS kernels behind ``box.multibox_detection`` and
 ``SODa.predict``, against the reference-generated goldens and the host path."""
+import os
+
 import pytest
 import torch
+
+from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -120,3 +124,62 @@ def test_event_batcher_matches_oracle_and_feeds_the_model(pkg):
         a = m(X)
         b = m(torch.from_numpy(X_ref).cuda())
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_roi_assign_kernel_matches_reference_vectors(hip_lib, golden_dir):
+    """snn_roi_assign (one block per sample) against vectors produced by the reference's own utils/roi.py: class labels
+    and masks bit for bit (plain labels and labels with -1 padding rows: the reference gives every padding ROW an
+    anchor too), offsets to the last bit except for the device logf (<= 2 ulp)."""
+    import numpy as np
+    from snn_for_object_detection_amd.roi import RoI
+    z = np.load(os.path.join(golden_dir, "detect_roi.npz"))
+    anchors = torch.from_numpy(np.load(os.path.join(golden_dir, "detect_anchors.npz"))["anchors_gen1"]).cuda()
+    for tag in ("plain", "padded"):
+        off, mask, cls = RoI(float(z["iou_threshold"]))(anchors, torch.from_numpy(z[f"labels_{tag}"]).cuda())
+        assert cls.dtype == torch.int64 and torch.equal(cls.cpu(), torch.from_numpy(z[f"cls_{tag}"])), tag
+        assert torch.equal(mask.cpu(), torch.from_numpy(z[f"mask_{tag}"])), tag
+        want = torch.from_numpy(z[f"offset_{tag}"])
+        assert torch.equal(off.cpu()[..., :2], want[..., :2]), tag                      # 10 * dxy / wh: exact
+        assert torch.allclose(off.cpu(), want, rtol=3e-7, atol=1e-6), tag               # 5 * log(...)
+
+
+def test_detection_loss_kernels_match_torch(hip_lib):
+    """snn_det_loss_fwd / _bwd against the reference's torch expression (models/soda.py:259-281): loss within 1e-6
+    relative, gradients within 1e-5; a sample set without positives gives NaN on both sides."""
+    from snn_for_object_detection_amd import functional as HF
+    torch.manual_seed(21)
+    for B, A, K in ((3, 1357, 3), (2, 4001, 8)):
+        cls_p = torch.randn(B, A, K, device="cuda").requires_grad_()
+        box_p = torch.randn(B, A, 4, device="cuda").requires_grad_()
+        labels = (torch.rand(B, A, device="cuda") < 0.02).long() * torch.randint(1, K, (B, A), device="cuda")
+        mask = (labels > 0).float().unsqueeze(-1).repeat(1, 1, 4)
+        mask[0, 5] = 1.0                                       # the padded-label quirk: class 0 with a box mask
+        offset = torch.randn(B, A, 4, device="cuda") * mask
+        ratio = 0.04
+        loss = HF.detection_loss(cls_p, box_p, offset, mask, labels, ratio)
+        loss.backward()
+        cr, br = cls_p.detach().clone().requires_grad_(), box_p.detach().clone().requires_grad_()
+        ce = torch.nn.functional.cross_entropy(cr.reshape(-1, K), labels.reshape(-1), reduction="none")
+        pos = labels.reshape(-1) > 0
+        ref = ce[pos].mean() * ratio + ce[~pos].mean() * (1 - ratio) + torch.nn.functional.l1_loss(br * mask, offset * mask)
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+        assert rel_err(cls_p.grad, cr.grad) < 1e-5 and rel_err(box_p.grad, br.grad) < 1e-5
+    none = HF.detection_loss(cls_p.detach(), box_p.detach(), offset * 0, mask * 0, labels * 0, ratio)
+    assert torch.isnan(none)
+
+
+def test_small_gemm_matches_torch(hip_lib):
+    from snn_for_object_detection_amd import functional as HF
+    torch.manual_seed(22)
+    for M, N, K in ((64, 32, 64), (128, 256, 64), (37, 19, 250)):
+        a, b = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
+        want = a.double() @ b.double()
+        for ta, tb in ((False, False), (True, False), (False, True), (True, True)):
+            am = a.t().contiguous() if ta else a
+            bm = b.t().contiguous() if tb else b
+            c = torch.full((M, N), float("nan"), device="cuda")
+            HF._small_gemm(am, ta, bm, tb, c, 0)
+            assert rel_err(c, want) < 1e-6, (M, N, K, ta, tb)
+            HF._small_gemm(am, ta, bm, tb, c, 1)
+            assert rel_err(c, 2 * want) < 1e-6

@@ -94,7 +94,7 @@ def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, s
             loss.backward()
             losses.append(loss.item())
         want = {n: sum(dict(o.named_parameters())[n].grad for o in replicas) / world
-                for n, _ in replicas[0].named_parameters()}
+                for n, p0 in replicas[0].named_parameters() if p0.requires_grad}
         bn_ref = replicas[0]          # rank 0's buffers are what every rank holds after the step (DDP broadcast_buffers)
     else:
         o = oracle_replica()
@@ -106,7 +106,7 @@ def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, s
             losses.append(o._loss((preds[0], preds[1][sl], preds[2][sl]), labels))
         (sum(losses) / world).backward()
         losses = [l.item() for l in losses]
-        want = {n: p.grad for n, p in o.named_parameters()}
+        want = {n: p.grad for n, p in o.named_parameters() if p.requires_grad}
         bn_ref = o
     for k in range(world):
         assert abs(r[k]["loss"] - losses[k]) <= 1e-4 * abs(losses[k]), (k, r[k]["loss"], losses[k])
