@@ -48,7 +48,7 @@ CONFIGS = {
                    label="deep backbone 12 x {Conv(64,3), Norm, LIF} on GEN1 304x240"),
 }
 # significant bits of one product of each convolution arithmetic (include/snn_hip.h, SNN_PREC_*)
-PRODUCT_BITS = {"fp32": 24, "fp16x3": 22, "bf16x6": 24, "bf16x3": 16}
+PRODUCT_BITS = {"fp32": 24, "fp16x3": 22, "bf16x6": 24, "bf16x3": 16, "bf16": 8}
 
 
 def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
@@ -57,6 +57,8 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     backward = (kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
                 or kernel.endswith(", true>"))  # k_conv_direct3<BN, WM, WN, DGRAD>
     prec = bwd_prec if backward else fwd_prec
+    if prec == "bf16":
+        return PEAK_BF16_MATRIX_TFLOPS, "bf16 dense MFMA, one product"
     if prec == "bf16x3":
         return PEAK_BF16_MATRIX_TFLOPS / 3.0, "bf16 dense MFMA / 3 products"
     if prec == "bf16x6":
@@ -184,11 +186,12 @@ def main():
     ap.add_argument("--classes", type=int, default=None)
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference's config.yaml:76 (off by default, N>1 only)")
-    ap.add_argument("--forward-precision", choices=("fp16x3", "bf16x6", "fp32"), default="fp16x3",
+    ap.add_argument("--forward-precision", choices=("fp16x3", "bf16x6", "fp32", "bf16"), default="fp16x3",
                     help="forward conv arithmetic: fp16x3 = 2 fp16 pieces, 3 products (fp32-grade for |x| < 4094); "
-                         "bf16x6 = 3 bf16 pieces, 6 products (fp32-grade, any range); fp32 = exact fp32 MFMA")
-    ap.add_argument("--backward-precision", choices=("bf16x3", "fp32"), default="bf16x3",
-                    help="arithmetic of the backward convolutions")
+                         "bf16x6 = 3 bf16 pieces, 6 products (fp32-grade, any range); fp32 = exact fp32 MFMA; "
+                         "bf16 = the labelled THROUGHPUT mode (operands rounded to bf16, one product; not parity)")
+    ap.add_argument("--backward-precision", choices=("bf16x3", "fp32", "bf16"), default="bf16x3",
+                    help="arithmetic of the backward convolutions (bf16 = throughput mode, one product)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
@@ -349,7 +352,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             # fp32 tensors and fp32 accumulation in every mode; "f32" alone only when the products are exact fp32 too
-            "dtype": "f32" if exact else "f32 (16-bit split products)",
+            "dtype": "f32" if exact else ("bf16 products, f32 accumulate / storage (throughput mode, not parity)"
+                                          if "bf16" in (args.forward_precision, args.backward_precision)
+                                          else "f32 (16-bit split products)"),
             "arithmetic_bits": {"storage": 32, "accumulate": 32,
                                 "forward_product": PRODUCT_BITS[args.forward_precision],
                                 "backward_product": PRODUCT_BITS[args.backward_precision]},
@@ -367,10 +372,12 @@ def main():
                                            "pre-scaling, hh+hl+lh; fp32-grade: rel 5e-7 vs fp64, same as the fp32 MFMA)",
                                  "bf16x6": "bf16x6 split products (3-way bf16 split of both operands, fp32-grade: "
                                            "rel 5e-7 vs fp64, same as the fp32 MFMA)",
+                                 "bf16": "bf16 single product (operands rounded to 8 significant bits: throughput mode)",
                                  "fp32": "exact fp32 MFMA"}[args.forward_precision]
                               + "; backward conv "
-                              + ("bf16x3 split products (hi*hi+hi*lo+lo*hi, rel 1e-5)"
-                                 if args.backward_precision == "bf16x3" else "exact fp32 MFMA"),
+                              + {"bf16x3": "bf16x3 split products (hi*hi+hi*lo+lo*hi, rel 1e-5)",
+                                 "bf16": "bf16 single product (throughput mode)",
+                                 "fp32": "exact fp32 MFMA"}[args.backward_precision],
                 "loss": float(loss.item()),
                 "peak_hbm_gib": peak_gib,
             },

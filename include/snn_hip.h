@@ -58,8 +58,12 @@ enum {
  *                   contract: |x| < 4094 and |w| < 255 (beyond: inf/NaN in the output - visible, not silent);
  *                   values below |x| = 0.008 / |w| = 5e-4 keep an ABSOLUTE accuracy of 4e-9 / 2e-10 instead of 22
  *                   bits.  Default of the forward convolution (inputs are spikes / normalised activations).     fwd
+ *   SNN_PREC_BF16X1 the opt-in THROUGHPUT mode ("bf16" of BASELINE configs[1]): every operand is rounded once to bf16
+ *                   and multiplied as it is - one product, fp32 accumulation, fp32 tensors in HBM.  Relative error
+ *                   2^-9 per product: NOT a parity mode (spike trains diverge from the fp32 reference within a few
+ *                   layers; loss and gradients to ~1e-2).  Never a default.                     fwd, dgrad, wgrad
  * The mode is an argument of every call - the library keeps no process-wide arithmetic state. */
-enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4 };
+enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4, SNN_PREC_BF16X1 = 5 };
 
 /* flags of snn_affine_neuron_bwd */
 enum { SNN_SCAN_WIDE_ADDRESSING = 1 /* use 64-bit pointer addressing even when one timestep of every tensor fits the

@@ -16,7 +16,7 @@ NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE =
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 5
-PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3 = 0, 1, 3, 4   # SNN_PREC_* of include/snn_hip.h
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1 = 0, 1, 3, 4, 5   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING = 1
 
 

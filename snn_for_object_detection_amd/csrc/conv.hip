@@ -101,6 +101,9 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 //   v_mfma_f32_32x32x16_f16: relative error 2^-22, fp32-grade like bf16 x 6 at HALF its matrix work and two LDS
 //   images instead of three.  fp16 has the range for forward values (|x| < 65504; activations of a normalised
 //   spiking net are O(1), weights are pre-scaled by 2^8), not for gradients - the backward kernels stay on bf16.
+// SPLIT = 5: "bf16 x 1": the opt-in THROUGHPUT mode - every operand is rounded once to bf16 (8 significant bits) and
+//   multiplied as it is: one product, fp32 accumulation and storage.  Not a parity mode (relative error 2^-9 per
+//   product); tolerance stated in tests/test_gpu_bf16_mode.py.
 // SPLIT = 3: "bf16 x 6": three-way split x = h + m + l (24 significant bits, i.e. the fp32 value itself) and the
 //   six products hh + hm + mh + mm + hl + lh; the dropped terms are 2^-25 relative - fp32-grade accuracy at
 //   16/6 of the fp32 matrix rate.
@@ -118,10 +121,12 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int NPIECE = SPLIT == 3 ? 3 : 2;  // 16-bit images per operand
+    constexpr int NPIECE = SPLIT == 3 ? 3 : (SPLIT == 5 ? 1 : 2);  // 16-bit images per operand
     constexpr int A_BYTES = SPLIT ? NPIECE * BM * LDB * 2 : BM * LDK * 4;
     constexpr int B_BYTES = SPLIT ? NPIECE * BN * LDB * 2 : BN * LDK * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+    constexpr int STAGE_BYTES = 4 * 32 * (TN * 32 + 4) * 4;   // epilogue: 32 staged rows per wave (see below)
+    constexpr int SMEM_BYTES = A_BYTES + B_BYTES > STAGE_BYTES ? A_BYTES + B_BYTES : STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = reinterpret_cast<float*>(smem + A_BYTES);
     __bf16* Ah = reinterpret_cast<__bf16*>(smem);                 // [BM][LDB] high parts
@@ -378,9 +383,17 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         // k+2.  Between the two barriers only the LDS writes remain.  Measured without this (convert + write
         // between the barriers): MFMA pipe busy 36 % even with the global loads removed.
         constexpr int NP = NPIECE;                      // 16-bit images per operand
-        constexpr int NPROD = SPLIT == 3 ? 6 : 3;       // MFMA products per accumulator and k16
+        constexpr int NPROD = SPLIT == 3 ? 6 : (SPLIT == 5 ? 1 : 3);   // MFMA products per accumulator and k16
         bf16x4 pa[4][NP], pb[BROWS][NP];                // [.][0] hi, [.][1] lo, [.][2] mid
         auto convert = [&](const f32x4& v, bf16x4* out, float scale) {
+            if constexpr (SPLIT == 5) {  // one bf16 piece: round to nearest even
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const bf16x2 p = __builtin_convertvector(f32x2{v[e], v[e + 1]}, bf16x2);
+                    out[0][e] = p[0]; out[0][e + 1] = p[1];
+                }
+                return;
+            }
             if constexpr (SPLIT == 4) {  // fp16 pieces (v_cvt_pk_f16_f32); the residual x - hi is exact in fp32
                 u32x2 hi, lo;
 #pragma unroll
@@ -419,15 +432,15 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             for (int j = 0; j < 4; ++j) {
                 const int o = (lr + 32 * j) * LDB + kq;
                 *reinterpret_cast<bf16x4*>(&Ah[o]) = pa[j][0];
-                *reinterpret_cast<bf16x4*>(&Al[o]) = pa[j][1];
-                if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&Am[o]) = pa[j][2];
+                if constexpr (NP >= 2) *reinterpret_cast<bf16x4*>(&Al[o]) = pa[j][1];
+                if constexpr (NP >= 3) *reinterpret_cast<bf16x4*>(&Am[o]) = pa[j][2];
             }
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
                 const int o = (lr + 32 * j) * LDB + kq;
                 *reinterpret_cast<bf16x4*>(&Bh[o]) = pb[j][0];
-                *reinterpret_cast<bf16x4*>(&Bl[o]) = pb[j][1];
-                if (SPLIT == 3) *reinterpret_cast<bf16x4*>(&Bm[o]) = pb[j][2];
+                if constexpr (NP >= 2) *reinterpret_cast<bf16x4*>(&Bl[o]) = pb[j][1];
+                if constexpr (NP >= 3) *reinterpret_cast<bf16x4*>(&Bm[o]) = pb[j][2];
             }
         };
         auto mfma_group = [&](int ks) {  // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
@@ -436,20 +449,24 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             for (int i = 0; i < TM; ++i) {
                 const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
                 ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
-                if (SPLIT == 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
+                if constexpr (NP >= 2) al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                if constexpr (NP >= 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int off = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + 8 * h;
                 bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[off]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
-                if (SPLIT == 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
+                if constexpr (NP >= 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[off]);
+                if constexpr (NP >= 3) bm[j] = *reinterpret_cast<const bf16x8*>(&Bm[off]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {  // small terms first
+                    if constexpr (SPLIT == 5) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        continue;
+                    }
                     if constexpr (SPLIT == 4) {
                         const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]), xal = __builtin_bit_cast(f16x8, al[i]);
                         const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         };
         constexpr int NM = TM * TN * NPROD;              // MFMAs per k16 group
         constexpr int NREAD = (TM + TN) * NP;            // ds_read_b128 per k16 group
-        constexpr int CONV_OPS = SPLIT == 3 ? 24 : 14;   // VALU per converted f32x4 (approx.)
+        constexpr int CONV_OPS = SPLIT == 3 ? 24 : (SPLIT == 5 ? 2 : 14);   // VALU per converted f32x4 (approx.)
         constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM, VPG_B = (BROWS * CONV_OPS + NM - 1) / NM;
         if (g.Ktot > 0) {
             // both first tiles are requested back to back (the accumulators are not live yet, registers are free):
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     constexpr int EW = TN * 32 + 4;   // staged row length in floats
     constexpr int LPR = TN * 8;       // lanes per staged row (4 floats each)
     constexpr int RPP = 64 / LPR;     // rows per pass
-    static_assert(4 * 32 * EW * 4 <= A_BYTES + B_BYTES, "epilogue staging does not fit the operand tiles");
+    static_assert(4 * 32 * EW * 4 <= SMEM_BYTES, "epilogue staging does not fit the operand tiles");
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
     const bool ovec = g.out_vec != 0;
 #pragma unroll
@@ -895,7 +912,7 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
 //     address arithmetic; dy rows past the split's last pixel fall off the end of the buffer resource;
 //   * tile k+1 is converted to its bf16 pieces in the shadow of tile k's MFMAs and the loads of tile k+2 are
 //     issued before the barrier; between the two barriers only the LDS writes remain.
-template <int TM, int TN, int WM, int WN, int WBK>
+template <int TM, int TN, int WM, int WN, int WBK, bool ONE>   // ONE: bf16 x 1 (hi pieces only, one product)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, WgradGeom g) {
@@ -910,9 +927,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     constexpr int GPP = kThreads / NQ;
     constexpr int DQ = (DG + GPP - 1) / GPP, XQ = (XG + GPP - 1) / GPP;
     __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDW];
-    __shared__ __attribute__((aligned(16))) __bf16 Dl[BMc * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Dl[ONE ? 8 : BMc * LDW];
     __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDW];
-    __shared__ __attribute__((aligned(16))) __bf16 Xl[BNk * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[ONE ? 8 : BNk * LDW];
     __shared__ __attribute__((aligned(16))) int Pinfo[2][WBK][4];  // {byte offset of the pixel origin, y0, x0, valid}
 
     const int tid = threadIdx.x;
@@ -1041,10 +1058,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
                 bf16x2 pp = __builtin_convertvector(rest, bf16x2);
                 const unsigned bits = __builtin_bit_cast(unsigned, pp);
                 out[c][0][e] = pp[0]; out[c][0][e + 1] = pp[1];
-                rest[0] -= __builtin_bit_cast(float, bits << 16);
-                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
-                pp = __builtin_convertvector(rest, bf16x2);
-                out[c][1][e] = pp[0]; out[c][1][e + 1] = pp[1];
+                if constexpr (!ONE) {
+                    rest[0] -= __builtin_bit_cast(float, bits << 16);
+                    rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+                    pp = __builtin_convertvector(rest, bf16x2);
+                    out[c][1][e] = pp[0]; out[c][1][e + 1] = pp[1];
+                }
             }
     };
     auto write_tiles = [&]() {
@@ -1054,7 +1073,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     *reinterpret_cast<bf16x4*>(&Dh[(d_cq[q] + c) * LDW + quad * 4]) = pd[q][c][0];
-                    *reinterpret_cast<bf16x4*>(&Dl[(d_cq[q] + c) * LDW + quad * 4]) = pd[q][c][1];
+                    if constexpr (!ONE) *reinterpret_cast<bf16x4*>(&Dl[(d_cq[q] + c) * LDW + quad * 4]) = pd[q][c][1];
                 }
             }
 #pragma unroll
@@ -1063,7 +1082,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     *reinterpret_cast<bf16x4*>(&Xh[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][0];
-                    *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][1];
+                    if constexpr (!ONE) *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][1];
                 }
             }
     };
@@ -1082,25 +1101,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         for (int i = 0; i < TM; ++i) {
             const int off = ((wm * TM + i) * 32 + r) * LDW + ks * 16 + 8 * h;
             ah[i] = *reinterpret_cast<const bf16x8*>(&Dh[off]);
-            al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
+            if constexpr (!ONE) al[i] = *reinterpret_cast<const bf16x8*>(&Dl[off]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int off = ((wn * TN + j) * 32 + r) * LDW + ks * 16 + 8 * h;
             bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-            bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
+            if constexpr (!ONE) bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                if constexpr (!ONE) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
     };
-    constexpr int NM = TM * TN * 3;
-    constexpr int NREAD = (TM + TN) * 2;
+    constexpr int NM = TM * TN * (ONE ? 1 : 3);
+    constexpr int NREAD = (TM + TN) * (ONE ? 1 : 2);
     constexpr int VPG_D = (DQ * 56 + NM - 1) / NM, VPG_X = (XQ * 56 + NM - 1) / NM;
 
     decode(0);
@@ -1256,7 +1277,7 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else if (vec)                                                                                       \
-            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, (SPLIT == 4 ? 3 : SPLIT), false>), grid, dim3(kThreads), 0, \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, (SPLIT == 4 ? 3 : (SPLIT == 5 ? 2 : SPLIT)), false>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else                                                                                                \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, false, 0, false>), grid, dim3(kThreads), 0, st, \
@@ -1819,8 +1840,9 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                               const float* addend, int64_t ld_addend, int precision, void* stream) {
     SNN_REQUIRE(x && w && y, "snn_conv2d_fwd: null pointer");
-    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3,
-                "snn_conv2d_fwd: precision must be SNN_PREC_FP32, SNN_PREC_BF16X6 or SNN_PREC_FP16X3 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3 ||
+                    precision == SNN_PREC_BF16X1,
+                "snn_conv2d_fwd: precision must be SNN_PREC_FP32, _BF16X6, _FP16X3 or _BF16X1 (got %d)", precision);
     const int fwd_split = precision;
     if (check_conv_shape("snn_conv2d_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout, "snn_conv2d_fwd: pixel stride smaller than channel count");
@@ -1852,6 +1874,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
                                              nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
         if (rc >= 0) return rc;
     }
+    if (fwd_split == 5)
+        return launch_gather<false, 5>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 4)
         return launch_gather<false, 4>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 3)
@@ -1864,8 +1888,8 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
                                 const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2,
                                 int precision, void* stream) {
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
-    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3,
-                "snn_conv2d_dgrad: precision must be SNN_PREC_FP32 or SNN_PREC_BF16X3 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1,
+                "snn_conv2d_dgrad: precision must be SNN_PREC_FP32, SNN_PREC_BF16X3 or SNN_PREC_BF16X1 (got %d)", precision);
     const int bwd_split = precision;
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv2d_dgrad: addend2 pixel stride smaller than channel count");
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
@@ -1881,7 +1905,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     const bool split = bwd_split != 0;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {  // dx = conv(dy, mirrored taps of w^T)
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && bwd_split != SNN_PREC_BF16X1) {  // dx = conv(dy, mirrored taps of w^T)
         const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
                                             ld_addend, addend2, ld_addend2, (hipStream_t)stream, "snn_conv2d_dgrad");
         if (rc >= 0) return rc;
@@ -1898,10 +1922,13 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
-                                                    (hipStream_t)stream, "snn_conv2d_dgrad")
-                           : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
-                                                    (hipStream_t)stream, "snn_conv2d_dgrad");
+            int rc = bwd_split == SNN_PREC_BF16X1
+                         ? launch_gather<true, 5>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                  (hipStream_t)stream, "snn_conv2d_dgrad")
+                         : (split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                           (hipStream_t)stream, "snn_conv2d_dgrad")
+                                  : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                           (hipStream_t)stream, "snn_conv2d_dgrad"));
             if (rc) return rc;
         }
     return 0;
@@ -2013,8 +2040,8 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                                 int accumulate, float* workspace, int splitk, int precision, void* stream) {
     SNN_REQUIRE(x && dy && dw && workspace, "snn_conv2d_wgrad: null pointer");
-    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3,
-                "snn_conv2d_wgrad: precision must be SNN_PREC_FP32 or SNN_PREC_BF16X3 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1,
+                "snn_conv2d_wgrad: precision must be SNN_PREC_FP32, SNN_PREC_BF16X3 or SNN_PREC_BF16X1 (got %d)", precision);
     const int bwd_split = precision;
     if (check_conv_shape("snn_conv2d_wgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && lddy >= Cout, "snn_conv2d_wgrad: pixel stride smaller than channel count");
@@ -2041,7 +2068,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
             SNN_REQUIRE(splitk == hp.slabs, "snn_conv2d_wgrad: splitk %d, expected %d (snn_conv2d_wgrad_splitk)", splitk,
                         hp.slabs);
             const int rc = snn_wgrad_halo_launch(hp, x, ldx, dy, lddy, workspace, N, H, W, Cin, Ho, Wo, Cout, stride,
-                                                 (hipStream_t)stream);
+                                                 precision == SNN_PREC_BF16X1 ? 1 : 3, (hipStream_t)stream);
             if (rc == 0)
                 return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, hp.slabs, accumulate,
                                           (hipStream_t)stream);
@@ -2062,6 +2089,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     static const bool no_pipe = snn_tuning_env("SNN_WGRAD_NO_PIPE") != nullptr;  // tuning / bisecting aid
     const bool pipe = vec && bwd_split && !no_pipe && g.Mtot < 0x7fffffffLL && span_pix * ldx * 4 < 0x7fffffffLL &&
                       g.pix_per_split * lddy * 4 < 0x7fffffffLL && (int64_t)H * W * ldx * 4 < 0x7fffffffLL;
+    const bool one = precision == SNN_PREC_BF16X1;
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
     g.splitk = splitk;
@@ -2071,11 +2099,17 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (pipe && wbk == 64)                                                                                 \
-            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64>), grid, dim3(kThreads), 0, st, x, dy, \
+        if (pipe && one && wbk == 64)                                                                          \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, true>), grid, dim3(kThreads), 0, st, x, dy, \
+                               workspace, g);                                                                  \
+        else if (pipe && one)                                                                                  \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32, true>), grid, dim3(kThreads), 0, st, x, dy, \
+                               workspace, g);                                                                  \
+        else if (pipe && wbk == 64)                                                                            \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, false>), grid, dim3(kThreads), 0, st, x, dy, \
                                workspace, g);                                                                  \
         else if (pipe)                                                                                         \
-            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32>), grid, dim3(kThreads), 0, st, x, dy, \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32, false>), grid, dim3(kThreads), 0, st, x, dy, \
                                workspace, g);                                                                  \
         else if (vec) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, WM_, WN_, true>), grid, dim3(kThreads), 0, st, x,  \
                                     dy, workspace, g);                                                         \

@@ -68,7 +68,7 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 // used to size the workspace in that case - the caller checks the same conditions before planning)
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
-                          hipStream_t st);
+                          int nprod /* 3: bf16 x 3, 1: bf16 x 1 */, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -82,7 +82,7 @@ __device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
 }
 
-template <int WCO, int WK, int S>
+template <int WCO, int WK, int S, int NPROD>   // NPROD: 3 = bf16 x 3 (hi + lo pieces), 1 = bf16 x 1 (hi pieces only)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, HaloGeom g) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
             split_bf16(st[j][2], st[j][3], h1, l1);
             if (hl < g.halo) {
                 *reinterpret_cast<u32x2*>(smem + sp * 64 + sl8 * 8) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(smem + PLANE + sp * 64 + sl8 * 8) = u32x2{l0, l1};
+                if constexpr (NPROD == 3) *reinterpret_cast<u32x2*>(smem + PLANE + sp * 64 + sl8 * 8) = u32x2{l0, l1};
             }
         }
     };
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
                     const auto ph = (__attribute__((address_space(3))) s16x4*)(base + 256 * s);
                     const auto pl = (__attribute__((address_space(3))) s16x4*)(base + 256 * s + PLANE);
                     fh[buf][s] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ph);
-                    fl[buf][s] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pl);
+                    if constexpr (NPROD == 3) fl[buf][s] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(pl);
                 }
             };
             read_b(0, 0);
@@ -268,17 +268,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
                 if (t + 1 < 9) read_b(t + 1, (t + 1) & 1);
                 const int u = t & 1;
                 const bf16x8 Bh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fh[u][0], fh[u][1], 0, 1, 2, 3, 4, 5, 6, 7));
-                const bf16x8 Bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fl[u][0], fl[u][1], 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);  // small terms first
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
+                if constexpr (NPROD == 3) {
+                    const bf16x8 Bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fl[u][0], fl[u][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);  // small terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
             }
-            // schedule shape: [4 reads of tap t+1] then the 3 products of tap t
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            // schedule shape: [reads of tap t+1] then the products of tap t
+            constexpr int NRD = NPROD == 3 ? 4 : 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
             }
         }
         HSTAMP(1);
@@ -402,7 +405,7 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
-                          hipStream_t st) {
+                          int nprod, hipStream_t st) {
     // 32-bit byte offsets inside one image (buffer addressing)
     if ((int64_t)H * W * ldx * 4 >= 0x7fffffffLL || (int64_t)Ho * Wo * lddy * 4 >= 0x7fffffffLL) return -1;
     if (ldx % 4 != 0 || !aligned16(x)) return -1;
@@ -422,10 +425,14 @@ int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx
     dim3 grid((unsigned)nblocks);
 #define SNN_HALO_LAUNCH(WCO_, WK_)                                                                                  \
     do {                                                                                                            \
-        if (stride == 1)                                                                                            \
-            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        if (stride == 1 && nprod == 3)                                                                              \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 3>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (nprod == 3)                                                                                        \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 3>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (stride == 1)                                                                                       \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 1>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 1>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
     } while (0)
     if (p.wco == 4) SNN_HALO_LAUNCH(4, 1);
     else if (p.wco == 2) SNN_HALO_LAUNCH(2, 2);

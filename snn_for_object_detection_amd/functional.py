@@ -41,12 +41,16 @@ def neuron_params(dt: float = DEFAULT_DT) -> NeuronParams:
 #             "bf16x6" (three bf16 pieces, six products: fp32-grade for any range, half the speed),
 #             "fp32"   (exact fp32 MFMA, an fmaf chain);
 #   backward: "bf16x3" (default: bf16 hi + lo, hi*hi + hi*lo + lo*hi, relative error ~1e-5 of the exact product),
-#             "fp32".
+#             "fp32";
+#   both    : "bf16"   - the opt-in THROUGHPUT mode: operands rounded once to bf16, ONE product per multiply-add, fp32
+#             accumulation and fp32 tensors.  8 significant bits: not a parity mode and never a default (stated
+#             tolerances: tests/test_gpu_bf16_mode.py).
 # A layer overrides it with ``HipConv2d.forward_precision / .backward_precision`` (BlockGen sets "bf16x6" on
 # convolutions fed by an unbounded activation - ReLU / SiLU / SumPool / ConvLSTM - where the fp16 range contract of
 # "fp16x3" is not guaranteed by construction).
-FORWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x6": _hip.PREC_BF16X6, "fp16x3": _hip.PREC_FP16X3}
-BACKWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x3": _hip.PREC_BF16X3}
+FORWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x6": _hip.PREC_BF16X6, "fp16x3": _hip.PREC_FP16X3,
+                 "bf16": _hip.PREC_BF16X1}
+BACKWARD_MODES = {"fp32": _hip.PREC_FP32, "bf16x3": _hip.PREC_BF16X3, "bf16": _hip.PREC_BF16X1}
 DEFAULT_FORWARD_PRECISION = "fp16x3"
 DEFAULT_BACKWARD_PRECISION = "bf16x3"
 

@@ -548,7 +548,7 @@ def test_forward_precision_modes_against_fp64(HF, mode):
     finally:
         HF.set_forward_precision(prev)
     with pytest.raises(ValueError):
-        HF.set_forward_precision("bf16")
+        HF.set_forward_precision("bf16x2")
 
 
 def test_fp16x3_range_contract(HF):
