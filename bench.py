@@ -313,11 +313,17 @@ def main():
         name, row = max(table.items(), key=lambda kv: kv[1]["ms"])
         default_shape = (T, B, H, W, classes) == (cfg["T"], cfg["batch"], cfg["H"], cfg["W"], cfg["classes"])
         traffic, traffic_src = pmc_traffic(args.config, name) if default_shape else (None, {"note": "non-default shape"})
-        peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
+        if name.startswith("k_conv"):
+            peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
+            head = {"bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
+                    "unit": "TFLOP/s", "frac": row["tflops"] / peak}
+        else:  # the fused norm + neuron scans and the other pointwise kernels move bytes: priced against HBM
+            head = {"bound": "hbm", "kernel": name, "achieved": row["gbs"], "peak": PEAK_HBM_GBS,
+                    "peak_basis": "HBM3E 8 TB/s spec (6.3 TB/s measured copy rate); algorithmic bytes = 4 B per tensor "
+                                  "element the fused kernel must touch", "unit": "GB/s", "frac": row["gbs"] / PEAK_HBM_GBS}
         roofline = {
-            "bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
-            "unit": "TFLOP/s", "frac": row["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_src,
-            "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
+            **head, "traffic": traffic, "traffic_source": traffic_src,
+            "achieved_tflops": row["tflops"], "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
             "avg_launch_us": row["avg_us"], "launches_per_step": row["calls"] // 2,
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     }
     const unsigned fast_tw_n = DGRAD ? g.nkw : g.KW;
     const unsigned fast_tw_one = fast_tw_n == 1 ? 1u : 0u;  // magic_u32(1) is 0: q = umulhi(n, 0) + n
-    auto load_tiles_fast = [&](int k0n, f32x4 (&ra)[4], f32x4 (&rb)[BROWS]) {  // k0n is block-uniform: everything up to the per-row adds is scalar
+    // which = 1: the A rows, 2: the B rows, 3: both (the main loop requests each operand as soon as its previous
+    // registers have been converted, so a load has the rest of the k-step in flight before it is needed)
+    auto load_tiles_fast = [&](int k0n, f32x4 (&ra)[4], f32x4 (&rb)[BROWS], int which = 3) {  // k0n is block-uniform: everything up to the per-row adds is scalar
         const bool kin = k0n < g.Ktot;
         const int tap = (int)__umulhi((unsigned)k0n, g.magic_ic);  // IC >= 32 here
         const int c0 = k0n - tap * g.IC;
@@ -268,15 +270,19 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             wcol0 = ((g.kh0 + g.stride * th) * g.KW + (g.kw0 + g.stride * tw)) * g.IC + c0;
         }
         const int tbit = kin ? tap : 31;  // bit 31 is never set: a prefetch past the last k-step loads zeros
+        if (which & 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int voff = ((a_mask[j] >> tbit) & 1u) ? a_rel[j] + toff : -1;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
+            for (int j = 0; j < 4; ++j) {
+                const int voff = ((a_mask[j] >> tbit) & 1u) ? a_rel[j] + toff : -1;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
+            }
         }
-        const unsigned wb = (unsigned)wcol0 * 4u;
+        if (which & 2) {
+            const unsigned wb = (unsigned)wcol0 * 4u;
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j)
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(b_rel[j] + wb), 0, 0));
+            for (int j = 0; j < BROWS; ++j)
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)(b_rel[j] + wb), 0, 0));
+        }
     };
 
     auto load_tiles = [&](int k0) {
@@ -521,6 +527,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
+            load_tiles_fast(k0 + 2 * BK, ra, rb, 1);   // A of tile k+2: its registers are free since the conversion above
             mfma_group(1);
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
-            load_tiles_fast(k0 + 2 * BK, ra, rb);
+            load_tiles_fast(k0 + 2 * BK, ra, rb, 2);
             STAMP(2);
             __syncthreads();
             STAMP(3);

@@ -651,6 +651,7 @@ class SynapseState(NamedTuple):
 
 
 _SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
+SCAN_SEGMENT_T = 32   # backward scans of longer sequences run in segments of this many steps (None: one launch)
 SCAN_FLAGS = 0   # flags of snn_affine_neuron_bwd; tests set _hip.SCAN_WIDE_ADDRESSING to cover the 64-bit-pointer scan
 
 # Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores
@@ -807,20 +808,14 @@ class _AffineNeuron(Function):
             sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
         # eval-mode BN has no batch coupling: dy = alpha * gx, applied while gx is written
         apply_scale = 1 if (has_bn and use_running) else 0
-        if ctx.ckpt:
-            _hip.call("snn_lif_bwd_ckpt", g_out.data_ptr(), ldg, state.data_ptr(), y.data_ptr(), ldy, _ptr(g_vT),
-                      _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0),
-                      _ptr(sums), T, M, C, params, st)
-        else:
-            _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy,
-                      _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0),
-                      _ptr(g_i0), _ptr(sums), T, M, C, params, SCAN_FLAGS, st)
         dy = dgamma = dbias = None
+        coef = None
+        dg_ptr = db_ptr = None
+        acc_flag = 0
         if need_sums:
             coef = torch.empty((3, T, C), device=dev, dtype=_F32)
             g_slot, b_slot = ctx.slots
             slotted = (g_slot is not None or not need_gamma) and (b_slot is not None or not need_bias)
-            acc_flag = 0
             if slotted and (need_gamma or need_bias):
                 # gradients go straight into the flat gradient buffer; both share one accumulate flag
                 acc_flag = 1 if (g_slot or b_slot).written else 0
@@ -833,7 +828,46 @@ class _AffineNeuron(Function):
                 dgamma = torch.empty((C,), device=dev, dtype=_F32) if need_gamma else None
                 dbias = torch.empty((C,), device=dev, dtype=_F32) if need_bias else None
                 dg_ptr, db_ptr = _ptr(dgamma), _ptr(dbias)
-            if ctx.sync_group is None:
+        # Long sequences in SEGMENTS of SCAN_SEGMENT_T steps, last segment first.  The scan kernel keeps its per-(t, c)
+        # BatchNorm sums for ALL T steps in LDS (one slab per wave); at T = 128 that leaves room for 16 channels per
+        # block only, i.e. 64-byte runs per pixel - measured 2.6 TB/s against 4.6 at T = 32.  The recurrence crosses a
+        # segment boundary through (g_v, g_i), which the kernel already takes and returns: same values bit for bit.
+        segmented = (need_sums and has_state and not ctx.ckpt and ctx.sync_group is None and SCAN_SEGMENT_T
+                     and T > SCAN_SEGMENT_T)
+        if segmented:
+            fr_g, fr_y, fr_c = M * ldg * 4, M * ldy * 4, M * C * 4    # bytes per timestep of g_out / y / dense tensors
+            gv_in, gi_in = g_vT, g_iT
+            first = True
+            for t1 in range(T, 0, -SCAN_SEGMENT_T):
+                t0 = max(0, t1 - SCAN_SEGMENT_T)
+                ts = t1 - t0
+                last = t0 == 0
+                gv_out = g_v0 if (last and g_v0 is not None) else torch.empty((B, H, W, C), device=dev, dtype=_F32)
+                gi_out = g_i0 if (last and g_i0 is not None) else torch.empty((B, H, W, C), device=dev, dtype=_F32)
+                n_sums = _hip.query("snn_affine_neuron_bwd_sums_size", ts, M, C)
+                seg_sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
+                tc = t0 * C * 4
+                _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr() + t0 * fr_g, ldg,
+                          None if state is None else state.data_ptr() + t0 * fr_c, y.data_ptr() + t0 * fr_y, ldy,
+                          _ptr(gv_in), _ptr(gi_in), None if alpha is None else alpha.data_ptr() + tc,
+                          None if beta is None else beta.data_ptr() + tc, apply_scale, gx.data_ptr() + t0 * fr_c,
+                          gv_out.data_ptr(), gi_out.data_ptr(), seg_sums.data_ptr(), ts, M, C, params, SCAN_FLAGS, st)
+                _hip.call("snn_bn_bwd_finalize", seg_sums.data_ptr(), ts, M, C, _ptr(gamma), mean.data_ptr() + tc,
+                          invstd.data_ptr() + tc, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
+                          coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)
+                gv_in, gi_in, first = gv_out, gi_out, False
+        elif ctx.ckpt:
+            _hip.call("snn_lif_bwd_ckpt", g_out.data_ptr(), ldg, state.data_ptr(), y.data_ptr(), ldy, _ptr(g_vT),
+                      _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0),
+                      _ptr(sums), T, M, C, params, st)
+        else:
+            _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy,
+                      _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0),
+                      _ptr(g_i0), _ptr(sums), T, M, C, params, SCAN_FLAGS, st)
+        if need_sums:
+            if segmented:
+                pass   # coefficients and parameter gradients were finalised per segment
+            elif ctx.sync_group is None:
                 _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
                           invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), dg_ptr,
                           db_ptr, acc_flag, st)

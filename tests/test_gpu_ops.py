@@ -66,6 +66,33 @@ def test_conv2d_fwd_bwd(HF, T, B, Cin, H, W, Cout, k, s):
     assert rel_err(wd.grad, wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("neuron", ["LIF", "LI"])
+def test_long_backward_scan_in_segments_equals_one_launch(HF, neuron):
+    """Sequences longer than SCAN_SEGMENT_T run their backward scan in segments (the per-(t, c) BatchNorm sums of a
+    launch live in LDS, and their footprint limits the channels per block): the carried (g_v, g_i) make the input
+    gradient identical bit for bit; the parameter gradients are summed in a different (fixed) order."""
+    from snn_for_object_detection_amd import _hip
+    kind = _hip.NEURON_LIF if neuron == "LIF" else _hip.NEURON_LI
+    torch.manual_seed(31)
+    T, B, C, H, W = 70, 2, 64, 12, 10
+    y0 = 2.0 * torch.randn(T, B, C, H, W) + 0.2
+    g = torch.randn(T, B, C, H, W).cuda()
+    gv = torch.randn(B, C, H, W).cuda()
+    results = []
+    for seg in (None, 32):
+        HF.SCAN_SEGMENT_T = seg
+        try:
+            bn = torch.nn.BatchNorm2d(C).cuda().train()
+            y = y0.cuda().requires_grad_()
+            out, state = HF.affine_neuron(y, kind, None, bn=bn)
+            results.append(torch.autograd.grad((out, state.v), (y, bn.weight, bn.bias), (g, gv)))
+        finally:
+            HF.SCAN_SEGMENT_T = 32
+    (gy_a, gw_a, gb_a), (gy_b, gw_b, gb_b) = results
+    assert torch.isfinite(gy_a).all() and rel_err(gy_b, gy_a) < 1e-6      # coefficients use t-ordered sums per segment
+    assert rel_err(gw_b, gw_a) < 1e-5 and rel_err(gb_b, gb_a) < 1e-5
+
+
 HALO_WGRAD_CASES = [
     # N, Cin, H, W, Cout, stride      (3x3, pad 1: the halo-resident weight gradient, csrc/wgrad_halo.hip, takes the
     # layers with at least 150 000 output pixels; the smaller cases below cover the implicit-GEMM path on the same shapes)
