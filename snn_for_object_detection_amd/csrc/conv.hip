@@ -253,8 +253,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     }
     const unsigned fast_tw_n = DGRAD ? g.nkw : g.KW;
     const unsigned fast_tw_one = fast_tw_n == 1 ? 1u : 0u;  // magic_u32(1) is 0: q = umulhi(n, 0) + n
-    // which = 1: the A rows, 2: the B rows, 3: both (the main loop requests each operand as soon as its previous
-    // registers have been converted, so a load has the rest of the k-step in flight before it is needed)
+    // which = 1: the A rows, 2: the B rows, 3: both
     auto load_tiles_fast = [&](int k0n, f32x4 (&ra)[4], f32x4 (&rb)[BROWS], int which = 3) {  // k0n is block-uniform: everything up to the per-row adds is scalar
         const bool kin = k0n < g.Ktot;
         const int tap = (int)__umulhi((unsigned)k0n, g.magic_ic);  // IC >= 32 here
@@ -527,7 +526,6 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
-            load_tiles_fast(k0 + 2 * BK, ra, rb, 1);   // A of tile k+2: its registers are free since the conversion above
             mfma_group(1);
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
@@ -539,7 +537,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
-            load_tiles_fast(k0 + 2 * BK, ra, rb, 2);
+            load_tiles_fast(k0 + 2 * BK, ra, rb);   // (requesting the A rows one MFMA group earlier: measured neutral)
             STAMP(2);
             __syncthreads();
             STAMP(3);

@@ -42,7 +42,7 @@ class FlatTrainer:
     """
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = True):
+                 process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise RuntimeError("model has no trainable parameters")
@@ -91,8 +91,10 @@ class FlatTrainer:
             self._offsets.append(self._offsets[-1] + p.numel())
         # BatchNorm buffers (running statistics, num_batches_tracked).  Without SyncBatchNorm every rank updates them
         # from its own shard; torch DDP (the reference's ``strategy: ddp``, config/config.yaml:35) broadcasts rank 0's
-        # buffers to all ranks (``broadcast_buffers=True``), so a checkpoint written by any rank holds the same
-        # statistics.  ``step()`` does the same with ONE broadcast of a flat copy (44 small tensors for TinyYolo).
+        # buffers to all ranks before every forward (``broadcast_buffers=True``), so a checkpoint written by any rank
+        # holds the same statistics.  Training itself never reads them (train-mode BatchNorm uses batch statistics),
+        # so the broadcast happens where it matters - ``sync_buffers()`` / ``checkpoint()`` before evaluating or
+        # saving - instead of ~130 tiny launches in every step; ``broadcast_buffers=True`` restores DDP's cadence.
         self._float_buffers = [b for b in model.buffers() if b.is_floating_point()]
         self._int_buffers = [b for b in model.buffers() if not b.is_floating_point() and b.numel() == 1]
         self.broadcast_buffers = broadcast_buffers
@@ -200,6 +202,13 @@ class FlatTrainer:
             self.sync_buffers()
 
     # ------------------------------------------------------------------ checkpoint / resume
+    def checkpoint(self, model: torch.nn.Module) -> Dict:
+        """``{"model": ..., "optimizer": ...}`` with the BatchNorm buffers made equal on all ranks first (rank 0's, as
+        torch DDP leaves them) - what a reference Lightning checkpoint carries."""
+        self.synchronize()
+        self.sync_buffers()
+        return {"model": {k: v.detach().clone() for k, v in model.state_dict().items()}, "optimizer": self.state_dict()}
+
     def state_dict(self) -> Dict:
         """Optimiser state in ``torch.optim.Adamax.state_dict()`` form: ``state[k] = {step, exp_avg, exp_inf}`` for the
         k-th trainable parameter (tensors in the parameter's LOGICAL shape), one param group.  Interchangeable with a

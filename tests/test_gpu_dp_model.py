@@ -55,6 +55,7 @@ def _worker(rank, world, port, out_dir, sync_bn):
         tr.synchronize()
         local = {n: g.detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
         tr.step()
+        tr.sync_buffers()                        # rank 0's BatchNorm buffers everywhere (DDP's broadcast_buffers)
         torch.cuda.synchronize()
         avg = {n: (g / world).detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
         torch.save({"start": start, "loss": loss.item(), "local": local, "avg": avg,
