@@ -37,12 +37,14 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, stamp: bool = False) -> str:
     """``tuning=True`` (``--tuning``): compile the bisecting / tuning environment knobs in (``-DSNN_TUNING``) and write
-    ``libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment."""
+    ``libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment.
+    ``stamp=True`` (``--stamp``): additionally ``-DSNN_STAMP`` (in-kernel cycle stamps of the conv main loop,
+    ``tools/stamp_conv.py``) -> ``libsnn_hip_stamp.so``."""
     hipcc = _hipcc()
-    if tuning:
-        return _build_tuning(hipcc, verbose)
+    if tuning or stamp:
+        return _build_tuning(hipcc, verbose, stamp)
     headers = [os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
@@ -69,9 +71,10 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> s
     return LIB_PATH
 
 
-def _build_tuning(hipcc: str, verbose: bool) -> str:
-    out = os.path.join(HERE, "libsnn_hip_tuning.so")
-    cmd = [hipcc, *FLAGS, "-DSNN_TUNING", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False) -> str:
+    out = os.path.join(HERE, "libsnn_hip_stamp.so" if stamp else "libsnn_hip_tuning.so")
+    cmd = [hipcc, *FLAGS, "-DSNN_TUNING", *(["-DSNN_STAMP"] if stamp else []), "-shared",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -81,4 +84,4 @@ def _build_tuning(hipcc: str, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv, stamp="--stamp" in sys.argv))

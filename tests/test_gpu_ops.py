@@ -104,6 +104,8 @@ HALO_WGRAD_CASES = [
     (1900, 256, 15, 19, 256, 2), # stride 2, odd sizes, eight input-channel tiles
     (1900, 128, 8, 10, 128, 1),  # one patch per image
     (2100, 32, 9, 8, 64, 1),     # images narrower than most patches
+    (3, 32, 90, 640, 32, 1),     # 1 Mpx-class rows: 40 column patches per row
+    (11, 64, 181, 320, 128, 2),  # 1 Mpx-class stride-2 layer, odd height
     (6, 128, 30, 38, 128, 1), (3, 64, 37, 52, 128, 2),   # below the size threshold: implicit-GEMM kernel
 ]
 
