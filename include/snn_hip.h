@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 5
+#define SNN_ABI_VERSION 6
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -120,11 +120,18 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
  * fwd / dgrad `addend` (may be NULL): a tensor of the result's shape with pixel stride ld_addend that is added
  *   in the epilogue (result = conv + addend); passing the destination itself accumulates in place.  This
  *   fuses the gradient sum of a tensor consumed by several branches (generator.py:181-187) into the dgrad.
- * wgrad accumulate != 0 : the result is added to dw instead of overwriting it. */
+ * wgrad accumulate != 0 : the result is added to dw instead of overwriting it.
+ * fwd `bn_partial` (may be NULL): the convolution is followed by a train-mode BatchNorm (layer_gen.py:211-214 after
+ *   :129-136) whose per-timestep statistics are then taken from the values on their way to the store instead of a
+ *   second pass over y.  The N frames are T = N / frames_per_step timesteps of frames_per_step frames; bn_partial
+ *   holds snn_conv2d_fwd_bn_partial_size() doubles; on return (host side, no synchronisation) bn_layout[0] =
+ *   chunks per timestep and bn_layout[1] = rows per chunk, the two layout arguments of snn_bn_stats_finalize /
+ *   snn_bn_stats_reduce.  bn_layout[0] == 0: this shape's kernel did not produce them - run snn_bn_stats. */
+size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step, int Ho, int Wo, int Cout);
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                   int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend, int precision,
-                   void* stream);
+                   int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend,
+                   double* bn_partial, int frames_per_step, int* bn_layout, int precision, void* stream);
 /* dgrad takes TWO optional addends (dx = conv^T(dy) + addend + addend2): a tensor consumed by a convolution, a
  * residual shortcut and a Dense pass-through (the YOLO bottleneck inside a C2f block) gets its whole gradient in one
  * epilogue instead of two extra add passes. */
@@ -148,10 +155,12 @@ int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, in
  * snn_bn_stats_finalize also performs the T sequential running-stat updates of one reference
  * forward (momentum 0.1, unbiased variance) when running_mean/var are non-NULL, and emits the
  * per-(t,c) affine  alpha = gamma*invstd, beta = bias - mean*alpha  that the scan consumes.
- * use_running != 0 (eval mode): alpha/beta come from the running statistics for every t. */
+ * use_running != 0 (eval mode): alpha/beta come from the running statistics for every t.
+ * chunks / rows_per_chunk describe the layout of `partial`: 0, 0 for the one snn_bn_stats writes, the two values
+ * snn_conv2d_fwd returned in bn_layout for partials that came out of a convolution epilogue. */
 size_t snn_bn_stats_partial_size(int T, int64_t M, int C);
 int snn_bn_stats(const float* y, int64_t ldy, int T, int64_t M, int C, double* partial, void* stream);
-int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C,
+int snn_bn_stats_finalize(const double* partial, int chunks, int rows_per_chunk, int T, int64_t M, int C,
                           const float* gamma, const float* bias, float eps, float momentum,
                           float* running_mean, float* running_var, int use_running,
                           float* mean, float* invstd, float* alpha, float* beta, void* stream);
@@ -159,7 +168,8 @@ int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C,
 /* SyncBatchNorm form (config.yaml:76) of the two steps above: reduce the chunk partials to sums[T][C][2]
  * (sum y, sum y^2), let the caller all-reduce that small tensor over the ranks, then finish from the global
  * sums over M_total = world * M pixels.  var_scratch: T*C doubles. */
-int snn_bn_stats_reduce(const double* partial, int T, int64_t M, int C, double* sums, void* stream);
+int snn_bn_stats_reduce(const double* partial, int chunks, int rows_per_chunk, int T, int64_t M, int C, double* sums,
+                        void* stream);
 int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total, int C,
                            const float* gamma, const float* bias, float eps, float momentum,
                            float* running_mean, float* running_var,

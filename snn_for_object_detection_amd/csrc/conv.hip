@@ -71,6 +71,10 @@ struct ConvGeom {
     int out_vec;  // output (and addend) rows may be stored 16 bytes per lane
     int nimg;     // images in the gathered tensor (FAST loader: extent of its buffer resource)
     int mtiles, mtiles_per_xcd, ntiles;  // XCD-aware tile order (see k_conv_gather)
+    // FWD only: statistics partials of the BatchNorm that follows (null: none), see stat_flush below
+    double* bn_partial;
+    int64_t bn_rows;   // output pixels per timestep (>= BM: a row tile meets at most two timesteps)
+    int bn_chunks;     // chunk slots per timestep
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -88,6 +92,47 @@ constexpr float kF16WeightScale = 256.0f;
 constexpr float kF16ActScale = 16.0f;
 constexpr float kF16Unscale = 1.0f / (kF16WeightScale * kF16ActScale);
 constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS images: 80 B keeps ds_read_b128 conflict-free
+
+// ---- BatchNorm statistics out of a forward epilogue.  The separate pass (snn_bn_stats) re-reads the whole layer
+// output from HBM; the epilogue has every value in registers on its way to the store.  Layout of the partials is the
+// one snn_bn_stats_finalize reads: partial[t][chunk][c][2] = (sum y, sum y^2) in fp64, a chunk being whatever set of
+// pixels of timestep t one block (tile) owns.  The MFMA accumulator layout already is "one channel per lane": lane
+// (r, h) of wave (wm, wn) holds channel (wn*TN + j)*32 + r of the 16 rows (wm*TM + i)*32 + (e&3) + 8*(e>>2) + 4*h,
+// so a lane sums its own registers, the two half-waves are added by one shuffle and the WM waves through LDS, in
+// that fixed order: deterministic, run to run.  (A convolution with statistics takes no addend: the sums are of the
+// accumulators, which then are the stored values.)
+//
+// red: 4 * TN * 32 * 2 doubles of LDS, free to use; dst: the [C][2] slot of this block's chunk.  Block-uniform call.
+template <int WM, int WN, int TN>
+__device__ __forceinline__ void stat_flush(double (&s)[TN], double (&q)[TN], double* red, double* __restrict__ dst,
+                                           int n0, int OC, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        s[j] += __shfl_xor(s[j], 32, 64);
+        q[j] += __shfl_xor(q[j], 32, 64);
+        if (lane < 32) {
+            red[((wave * TN + j) * 32 + lane) * 2 + 0] = s[j];
+            red[((wave * TN + j) * 32 + lane) * 2 + 1] = q[j];
+        }
+    }
+    __syncthreads();
+    if (tid < WN * TN * 32) {
+        const int wn = tid / (TN * 32), jr = tid % (TN * 32);
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm) {
+            const double* src = red + (((wm * WN + wn) * TN) * 32 + jr) * 2;
+            ss += src[0];
+            qq += src[1];
+        }
+        if (n0 + tid < OC) {
+            dst[(int64_t)(n0 + tid) * 2 + 0] = ss;
+            dst[(int64_t)(n0 + tid) * 2 + 1] = qq;
+        }
+    }
+    __syncthreads();
+}
 
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
@@ -635,6 +680,50 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     static_assert(4 * 32 * EW * 4 <= SMEM_BYTES, "epilogue staging does not fit the operand tiles");
     float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
     const bool ovec = g.out_vec != 0;
+    if (!DGRAD && g.bn_partial != nullptr) {
+        // BatchNorm partials: rows below `split` belong to timestep bn_t, the rest (up to Mtot) to bn_t + 1
+        const int64_t bn_t = m0 / g.bn_rows;
+        const int64_t split = (bn_t + 1) * g.bn_rows;
+        const bool whole = split >= m0 + BM && m0 + BM <= g.Mtot;   // one timestep, no rows past the end
+        double s_lo[TN], q_lo[TN], s_hi[TN], q_hi[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) s_lo[j] = q_lo[j] = s_hi[j] = q_hi[j] = 0.0;
+        if (whole) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const double d = (double)(SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e]);
+                        s_lo[j] += d;
+                        q_lo[j] = fma(d, d, q_lo[j]);
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const double d = (double)(SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e]);
+                        const double lo = m < split ? d : 0.0, hi = (m >= split && m < g.Mtot) ? d : 0.0;
+                        s_lo[j] += lo;
+                        q_lo[j] = fma(lo, lo, q_lo[j]);
+                        s_hi[j] += hi;
+                        q_hi[j] = fma(hi, hi, q_hi[j]);
+                    }
+        }
+        // the operand tiles are dead (the k loop ended with a barrier); the staging below starts after stat_flush's
+        double* red = reinterpret_cast<double*>(smem);
+        static_assert(4 * TN * 32 * 2 * 8 <= SMEM_BYTES, "statistics scratch does not fit");
+        const int chunk = (int)(m0 / BM - (bn_t * g.bn_rows) / BM);
+        stat_flush<WM, WN, TN>(s_lo, q_lo, red, g.bn_partial + ((bn_t * g.bn_chunks + chunk) * g.OC) * 2, n0, g.OC, tid);
+        if (split < m0 + BM && split < g.Mtot)   // this tile is also the first one of the next timestep
+            stat_flush<WM, WN, TN>(s_hi, q_hi, red, g.bn_partial + (((bn_t + 1) * g.bn_chunks) * g.OC) * 2, n0, g.OC,
+                                   tid);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1315,6 +1404,9 @@ struct DirectGeom {
     int tiles, tiles_per_xcd;
     int KtotFull;           // 9 * IC
     int out_vec;
+    // forward only: statistics partials of the BatchNorm that follows (null: none); a patch lies in ONE frame, so
+    // chunk = the patch's index among the patches of its timestep (frames per step * patches per image of them)
+    double* bn_partial;
 };
 constexpr int DPH = 8, DPW = 16, DHW = DPW + 2, DHALO = (DPH + 2) * DHW;  // 180 halo pixels
 constexpr int DHROWS = (DHALO + 7) / 8 * 8;                               // 184 LDS rows (whole groups of 8)
@@ -1597,7 +1689,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
             __syncthreads();
         }
         // ---- the next patch's first halo / weights are fetched while this patch's results are stored
-        const int e_img = img, e_oy0 = oy0, e_ox0 = ox0;
+        const int e_img = img, e_oy0 = oy0, e_ox0 = ox0, e_tile = tile;
         tile += nbx;
         const bool more = tile < t_hi;
         if (more) {
@@ -1610,6 +1702,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
         static_assert(4 * 32 * EW * 4 <= A_BYTES + B_BYTES, "epilogue staging does not fit");
         float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
         const bool ovec = g.out_vec != 0;
+        if (!FLIP && g.bn_partial != nullptr) {
+            // BatchNorm partials of this patch (one frame, hence one timestep); pixels past the image edge are dropped
+            const bool whole = e_oy0 + DPH <= g.IH && e_ox0 + DPW <= g.IW;
+            double ss[TN], qq[TN];
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) ss[j] = qq[j] = 0.0;
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int p = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = whole || (e_oy0 + (p >> 4) < g.IH && e_ox0 + (p & 15) < g.IW);
+                        const float v = SPLIT == 4 ? acc[i][j][e] * kF16Unscale : acc[i][j][e];
+                        const double d = ok ? (double)v : 0.0;
+                        ss[j] += d;
+                        qq[j] = fma(d, d, qq[j]);
+                    }
+            static_assert(4 * TN * 32 * 2 * 8 <= A_BYTES + B_BYTES, "statistics scratch does not fit");
+            // patches are numbered frame by frame, so [t][chunk] flattens to the patch number itself
+            stat_flush<WM, WN, TN>(ss, qq, reinterpret_cast<double*>(smem), g.bn_partial + ((int64_t)e_tile * g.OC) * 2,
+                                   0, g.OC, tid);
+        }
     #pragma unroll
         for (int i = 0; i < TM; ++i) {
     #pragma unroll
@@ -1655,7 +1771,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
 template <bool FLIP>
 static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* out, int64_t ldo, int64_t N, int H,
                           int W, int IC, int OC, int split, const float* addend, int64_t ld_add,
-                          const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
+                          const float* addend2, int64_t ld_add2, double* bn_partial, hipStream_t st, const char* name) {
     static const bool off = snn_tuning_env("SNN_CONV_NO_DIRECT") != nullptr;  // tuning / bisecting aid
     // measured: a win (12-15 %) for <= 32 output channels; at 64 the implicit-GEMM kernel is as fast or faster
     // (both are bound by LDS operand traffic there), so it stays the default; SNN_CONV_DIRECT_MAX_OC=64 to compare
@@ -1676,6 +1792,7 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
     g.KtotFull = 9 * IC;
     g.out_vec = (ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
+    g.bn_partial = bn_partial;
     // persistent: at most (CUs per XCD) x (resident blocks per CU) blocks per XCD
     const int resident = (OC <= 32 && split != 3) ? 3 : 2;
     int nbx = (snn_num_cu() / 8) * resident;
@@ -1727,6 +1844,11 @@ struct FirstGeom {
     int64_t ldx, ldy;
     int rows;  // N * Ho output rows
     int H, W, Ho, Wo, Cout, stride, pad;
+    // Rows are dealt to the blocks in groups: group q = blockIdx / group_blocks owns rows [q, q+1) * group_rows and
+    // its group_blocks blocks walk them with that stride.  One group (all rows) unless the forward pass also emits
+    // BatchNorm partials: then a group is a TIMESTEP and block j of it writes chunk j of partial[t][chunk][c][2].
+    int group_rows, group_blocks;
+    double* bn_partial;
 };
 
 // One block walks output ROWS (block-uniform row index: the image / row split and the vertical bounds are scalar
@@ -1738,6 +1860,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
     static_assert(CIN == 2, "float2 input pixels");
     constexpr int KT = KS * KS * CIN;
     __shared__ float red[WGRAD ? kThreads : 1][KT + 1];
+    __shared__ double sred[WGRAD ? 1 : kThreads][9];               // statistics of the forward pass (8 used: odd pitch)
     extern __shared__ __attribute__((aligned(16))) float2 srow[];   // [KS][W + 2 pad] input rows of the current output row
     const int cgs = g.Cout / 4;                       // channel groups: a power of two <= 64
     const int cg = threadIdx.x % cgs, pl = threadIdx.x / cgs, PP = kThreads / cgs;
@@ -1747,7 +1870,17 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
 #pragma unroll
         for (int k = 0; k < KT; ++k) wr[c][k] = WGRAD ? 0.f : w[(cg * 4 + c) * KT + k];
     const int ldx = (int)g.ldx, ldy = (int)g.ldy;
-    for (int r = blockIdx.x; r < g.rows; r += gridDim.x) {
+    const int grp = blockIdx.x / g.group_blocks, grp_j = blockIdx.x - grp * g.group_blocks;
+    const int r_end = (grp + 1) * g.group_rows < g.rows ? (grp + 1) * g.group_rows : g.rows;
+    // BatchNorm partials of the forward pass: a thread sums the <= ceil(Wo / PP) pixels it owns of ONE row in fp32
+    // (per-pixel fp64 work cost this kernel 30 %), the rows and everything above in fp64
+    // (the fp64 sums live in the thread's own LDS slot: in registers they cost the kernel a wave of occupancy)
+    const bool stats = !WGRAD && g.bn_partial != nullptr;
+    if (!WGRAD && stats) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sred[threadIdx.x][c] = 0.0;
+    }
+    for (int r = grp * g.group_rows + grp_j; r < r_end; r += g.group_blocks) {
         const int img = r / g.Ho, oy = r - img * g.Ho;
         const int iy0 = oy * g.stride - g.pad;
         const float* xrow[KS];
@@ -1773,6 +1906,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
         __syncthreads();
         const float* dyrow = WGRAD ? dy + (int64_t)r * g.Wo * g.ldy + cg * 4 : nullptr;
         float* yrow = WGRAD ? nullptr : out + (int64_t)r * g.Wo * g.ldy + cg * 4;
+        float row_s[4] = {0.f, 0.f, 0.f, 0.f}, row_q[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ox = pl; ox < g.Wo; ox += PP) {
             float2 taps[KS][KS];
 #pragma unroll
@@ -1802,7 +1936,34 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
             if (!WGRAD) {
                 f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
                 *reinterpret_cast<f32x4*>(yrow + ox * ldy) = o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    row_s[c] += acc[c];
+                    row_q[c] = fmaf(acc[c], acc[c], row_q[c]);
+                }
             }
+        }
+        if (!WGRAD && stats) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sred[threadIdx.x][c] += (double)row_s[c];
+                sred[threadIdx.x][4 + c] += (double)row_q[c];
+            }
+        }
+    }
+    if (!WGRAD && stats) {
+        // block sum over the PP pixel lanes of every channel, in lane order
+        __syncthreads();
+        if ((int)threadIdx.x < g.Cout) {
+            const int gq = threadIdx.x >> 2, c = threadIdx.x & 3;
+            double ss = 0.0, qq = 0.0;
+            for (int q = 0; q < PP; ++q) {
+                ss += sred[q * cgs + gq][c];
+                qq += sred[q * cgs + gq][4 + c];
+            }
+            double* dst = g.bn_partial + ((int64_t)blockIdx.x * g.Cout + threadIdx.x) * 2;  // [t][chunk] = block id
+            dst[0] = ss;
+            dst[1] = qq;
         }
     }
     if (WGRAD) {
@@ -1841,9 +2002,37 @@ static int first_layer_blocks(int64_t rows) {  // grid of the row-walking kernel
 }
 }  // namespace
 
+// Chunk slots per timestep of the three forward kernels' statistics partials (see stat_flush); 0: not produced.
+namespace {
+struct FirstGroups { int rows, blocks; };
+// first-layer kernel, one group of rows per timestep: an equal number of rows for every block of the group
+static FirstGroups first_layer_groups(int rows_per_step, int steps) {
+    int target = 8 * snn_num_cu() / (steps > 0 ? steps : 1);
+    if (target < 1) target = 1;
+    if (target > rows_per_step) target = rows_per_step;
+    const int per_block = (rows_per_step + target - 1) / target;
+    return {rows_per_step, (rows_per_step + per_block - 1) / per_block};
+}
+static int64_t gather_bn_chunks(int64_t rows_per_step) { return (rows_per_step + BM - 1) / BM + 1; }
+static int64_t direct_bn_chunks(int frames_per_step, int Ho, int Wo) {
+    return (int64_t)frames_per_step * ((Ho + DPH - 1) / DPH) * ((Wo + DPW - 1) / DPW);
+}
+}  // namespace
+
+extern "C" size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step, int Ho, int Wo, int Cout) {
+    if (N <= 0 || frames_per_step <= 0 || N % frames_per_step != 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return 0;
+    const int64_t T = N / frames_per_step, rows = (int64_t)frames_per_step * Ho * Wo;
+    int64_t chunks = gather_bn_chunks(rows);
+    const int64_t d = direct_bn_chunks(frames_per_step, Ho, Wo);
+    if (d > chunks) chunks = d;
+    if ((int64_t)frames_per_step * Ho > chunks) chunks = (int64_t)frames_per_step * Ho;   // first layer: <= one block per row
+    return (size_t)(T * chunks * Cout * 2);
+}
+
 extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                              const float* addend, int64_t ld_addend, int precision, void* stream) {
+                              const float* addend, int64_t ld_addend, double* bn_partial, int frames_per_step,
+                              int* bn_layout, int precision, void* stream) {
     SNN_REQUIRE(x && w && y, "snn_conv2d_fwd: null pointer");
     SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3 ||
                     precision == SNN_PREC_BF16X1,
@@ -1851,6 +2040,12 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     const int fwd_split = precision;
     if (check_conv_shape("snn_conv2d_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout, "snn_conv2d_fwd: pixel stride smaller than channel count");
+    SNN_REQUIRE(!bn_partial || (bn_layout && frames_per_step > 0 && N % frames_per_step == 0),
+                "snn_conv2d_fwd: statistics need bn_layout and a frames_per_step that divides N (%lld frames, %d per step)",
+                (long long)N, frames_per_step);
+    SNN_REQUIRE(!(bn_partial && addend), "snn_conv2d_fwd: statistics are of the convolution itself - no addend with bn_partial");
+    if (bn_layout) bn_layout[0] = bn_layout[1] = 0;
+    const int64_t step_rows = bn_partial ? (int64_t)frames_per_step * Ho * Wo : 0;
     ConvGeom g;
     g.Mtot = N * Ho * (int64_t)Wo;
     g.IH = H; g.IW = W; g.IC = Cin;
@@ -1861,23 +2056,46 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
     g.nimg = (int)N;
     g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
     g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
+    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
     if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 && aligned16(y) &&
         (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
-        FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
-        const int blocks = fg.rows < 8 * snn_num_cu() ? fg.rows : 8 * snn_num_cu();
+        FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), 0, nullptr};
+        int blocks = fg.rows < 8 * snn_num_cu() ? fg.rows : 8 * snn_num_cu();
+        fg.group_blocks = blocks;
+        if (bn_partial) {
+            const int steps = (int)(N / frames_per_step);
+            const FirstGroups fgr = first_layer_groups(frames_per_step * Ho, steps);
+            fg.group_rows = fgr.rows;
+            fg.group_blocks = fgr.blocks;
+            fg.bn_partial = bn_partial;
+            blocks = steps * fgr.blocks;
+            bn_layout[0] = fgr.blocks;
+        }
         hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
                            (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_fwd");
         return 0;
     }
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+        const int64_t chunks = bn_partial ? direct_bn_chunks(frames_per_step, Ho, Wo) : 0;
         const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, fwd_split, addend, ld_addend,
-                                             nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
-        if (rc >= 0) return rc;
+                                             nullptr, 0, chunks <= 0x7fffffff ? bn_partial : nullptr,
+                                             (hipStream_t)stream, "snn_conv2d_fwd");
+        if (rc >= 0) {
+            if (rc == 0 && bn_partial && chunks <= 0x7fffffff) bn_layout[0] = (int)chunks;
+            return rc;
+        }
+    }
+    if (bn_partial && step_rows >= BM && gather_bn_chunks(step_rows) <= 0x7fffffff) {
+        g.bn_partial = bn_partial;
+        g.bn_rows = step_rows;
+        g.bn_chunks = (int)gather_bn_chunks(step_rows);
+        bn_layout[0] = g.bn_chunks;
+        bn_layout[1] = BM;
     }
     if (fwd_split == 5)
         return launch_gather<false, 5>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
@@ -1907,12 +2125,14 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     g.ldi = lddy; g.ldo = lddx;
     g.KtotFull = KH * KW * Cout;
     g.nimg = (int)N;
+    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     const bool split = bwd_split != 0;
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && bwd_split != SNN_PREC_BF16X1) {  // dx = conv(dy, mirrored taps of w^T)
         const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
-                                            ld_addend, addend2, ld_addend2, (hipStream_t)stream, "snn_conv2d_dgrad");
+                                            ld_addend, addend2, ld_addend2, nullptr, (hipStream_t)stream,
+                                            "snn_conv2d_dgrad");
         if (rc >= 0) return rc;
     }
     // one launch per stride phase: each class multiplies only the taps that can reach it
@@ -2061,7 +2281,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     if (first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
         (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
-        FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad};
+        FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr};
         hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
                            (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");

@@ -140,19 +140,30 @@ __global__ void k_bn_stats_finalize(const double* __restrict__ partial, int chun
     beta[idx] = b - mu * a;
 }
 
+// Partials written by a convolution epilogue (conv.hip) come in row tiles of `rows_per_chunk` output pixels that do
+// not line up with the timesteps: chunk k of step t is the part of tile (first tile of t) + k that lies in t, so
+// the number of written slots differs by one between steps.  rows_per_chunk == 0: every one of `chunks` is written.
+__device__ __forceinline__ int chunks_of_step(int chunks, int rows_per_chunk, int t, int64_t M) {
+    if (rows_per_chunk <= 0) return chunks;
+    return (int)((((int64_t)t + 1) * M - 1) / rows_per_chunk - ((int64_t)t * M) / rows_per_chunk) + 1;
+}
+
 // One launch for the whole statistics second phase of a layer (was: finalize + running update, 27 us of two
-// latency-bound kernels 22 times per step).  One block per channel; 8 lanes share the chunk partials of one
-// (t, c) (each sums every 8th chunk in order, then a fixed xor tree), 32 timesteps per pass; thread 0 applies the T
+// latency-bound kernels 22 times per step).  One block per channel; SUB lanes share the chunk partials of one
+// (t, c) (each sums every SUB-th chunk in order, then a fixed xor tree), 32 timesteps per pass; thread 0 applies the T
 // sequential running-stat updates of one reference forward from LDS.  Fixed summation order: deterministic.
-__global__ __launch_bounds__(256) void k_bn_stats_finalize_fused(
-    const double* __restrict__ partial, int chunks, int T, int64_t M, int C, const float* __restrict__ gamma,
+// SUB = 8 for the few chunks snn_bn_stats writes, 32 for the hundreds of row tiles a convolution epilogue leaves.
+template <int SUB>
+__global__ __launch_bounds__(32 * SUB) void k_bn_stats_finalize_fused(
+    const double* __restrict__ partial, int chunks, int rows_per_chunk, int T, int64_t M, int C,
+    const float* __restrict__ gamma,
     const float* __restrict__ bias, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, int use_running, float* __restrict__ mean, float* __restrict__ invstd,
     float* __restrict__ alpha, float* __restrict__ beta) {
     __shared__ float sm_mean[32];
     __shared__ double sm_var[32];
     const int c = blockIdx.x;
-    const int sub = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int sub = threadIdx.x % SUB, tl = threadIdx.x / SUB;
     const bool update = !use_running && running_mean && running_var;
     float rm = 0.f, rv = 0.f;
     if (update && threadIdx.x == 0) {
@@ -166,13 +177,26 @@ __global__ __launch_bounds__(256) void k_bn_stats_finalize_fused(
         const int t = tb + tl;
         double s = 0.0, q = 0.0;
         if (!use_running && t < T) {
-            for (int k = sub; k < chunks; k += 8) {
-                const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
-                s += src[0];
-                q += src[1];
+            const int nk = chunks_of_step(chunks, rows_per_chunk, t, M);
+            const double* base = partial + ((int64_t)t * chunks * C + c) * 2;
+            int k = sub;
+            constexpr int U = SUB >= 32 ? 8 : 4;   // loads in flight (the loop is latency-bound), added in chunk order
+            for (; k + (U - 1) * SUB < nk; k += U * SUB) {
+                double2 p[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) p[u] = *reinterpret_cast<const double2*>(base + (int64_t)(k + u * SUB) * C * 2);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    s += p[u].x;
+                    q += p[u].y;
+                }
+            }
+            for (; k < nk; k += SUB) {
+                const double2 p0 = *reinterpret_cast<const double2*>(base + (int64_t)k * C * 2);
+                s += p0.x; q += p0.y;
             }
         }
-        for (int stride = 4; stride >= 1; stride >>= 1) {
+        for (int stride = SUB / 2; stride >= 1; stride >>= 1) {
             s += __shfl_xor(s, stride, 64);
             q += __shfl_xor(q, stride, 64);
         }
@@ -217,13 +241,14 @@ __global__ __launch_bounds__(256) void k_bn_stats_finalize_fused(
 }
 
 // chunk partials -> sums[t][c][2] (the quantity a SyncBatchNorm exchange all-reduces, config.yaml:76)
-__global__ void k_bn_stats_reduce(const double* __restrict__ partial, int chunks, int T, int C,
-                                  double* __restrict__ sums) {
+__global__ void k_bn_stats_reduce(const double* __restrict__ partial, int chunks, int rows_per_chunk, int T, int64_t M,
+                                  int C, double* __restrict__ sums) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * C) return;
     int t = idx / C, c = idx % C;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; ++k) {
+    const int nk = chunks_of_step(chunks, rows_per_chunk, t, M);
+    for (int k = 0; k < nk; ++k) {
         const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
         s += src[0];
         q += src[1];
@@ -1072,7 +1097,8 @@ extern "C" int snn_bn_stats(const float* y, int64_t ldy, int T, int64_t M, int C
     return 0;
 }
 
-extern "C" int snn_bn_stats_finalize(const double* partial, int T, int64_t M, int C, const float* gamma,
+extern "C" int snn_bn_stats_finalize(const double* partial, int chunks, int rows_per_chunk, int T, int64_t M, int C,
+                                     const float* gamma,
                                      const float* bias, float eps, float momentum, float* running_mean,
                                      float* running_var, int use_running, float* mean, float* invstd, float* alpha,
                                      float* beta, void* stream) {
@@ -1080,20 +1106,30 @@ extern "C" int snn_bn_stats_finalize(const double* partial, int T, int64_t M, in
     SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_stats_finalize: bad shape");
     SNN_REQUIRE(use_running ? (running_mean && running_var) : (partial != nullptr),
                 "snn_bn_stats_finalize: missing statistics source");
-    StatsPlan pl = stats_plan(T, M, C);
-    hipLaunchKernelGGL(k_bn_stats_finalize_fused, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, pl.chunks, T, M,
-                       C, gamma, bias, eps, momentum, running_mean, running_var, use_running, mean, invstd, alpha,
-                       beta);
+    SNN_REQUIRE(chunks >= 0 && rows_per_chunk >= 0 && (chunks > 0 || rows_per_chunk == 0),
+                "snn_bn_stats_finalize: bad partial layout (chunks %d, rows per chunk %d)", chunks, rows_per_chunk);
+    if (chunks == 0) chunks = stats_plan(T, M, C).chunks;   // the layout snn_bn_stats writes
+    if (chunks > 64 && !use_running)
+        hipLaunchKernelGGL(k_bn_stats_finalize_fused<32>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partial, chunks,
+                           rows_per_chunk, T, M, C, gamma, bias, eps, momentum, running_mean, running_var, use_running,
+                           mean, invstd, alpha, beta);
+    else
+        hipLaunchKernelGGL(k_bn_stats_finalize_fused<8>, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, chunks,
+                           rows_per_chunk, T, M, C, gamma, bias, eps, momentum, running_mean, running_var, use_running,
+                           mean, invstd, alpha, beta);
     SNN_CHECK_LAUNCH("snn_bn_stats_finalize");
     return 0;
 }
 
-extern "C" int snn_bn_stats_reduce(const double* partial, int T, int64_t M, int C, double* sums, void* stream) {
+extern "C" int snn_bn_stats_reduce(const double* partial, int chunks, int rows_per_chunk, int T, int64_t M, int C,
+                                   double* sums, void* stream) {
     SNN_REQUIRE(partial && sums && T > 0 && M > 0 && C > 0, "snn_bn_stats_reduce: bad arguments");
-    StatsPlan pl = stats_plan(T, M, C);
+    SNN_REQUIRE(chunks >= 0 && rows_per_chunk >= 0 && (chunks > 0 || rows_per_chunk == 0),
+                "snn_bn_stats_reduce: bad partial layout (chunks %d, rows per chunk %d)", chunks, rows_per_chunk);
+    if (chunks == 0) chunks = stats_plan(T, M, C).chunks;
     int n = T * C;
-    hipLaunchKernelGGL(k_bn_stats_reduce, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, pl.chunks,
-                       T, C, sums);
+    hipLaunchKernelGGL(k_bn_stats_reduce, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, chunks,
+                       rows_per_chunk, T, M, C, sums);
     SNN_CHECK_LAUNCH("snn_bn_stats_reduce");
     return 0;
 }

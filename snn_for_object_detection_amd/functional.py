@@ -10,6 +10,7 @@ not on a HIP device raise.
 """
 
 import collections
+import ctypes
 import os
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
@@ -461,7 +462,7 @@ class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None, bn_out=None):
         _require_device(x, "conv2d input")
         fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         _require_device(weight, "conv2d weight")
@@ -475,8 +476,15 @@ class _Conv2d(Function):
         w = weight.detach()
         w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
         y = _out_tensor(dest, T, B, Cout, Ho, Wo, x)
+        partial = layout = None
+        if bn_out is not None:  # a train-mode BatchNorm follows: its statistics come out of this kernel's epilogue
+            n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", T * B, B, Ho, Wo, Cout)
+            partial = torch.empty((n_part,), device=x.device, dtype=torch.float64)
+            layout = (ctypes.c_int * 2)()
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
-                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, fwd_prec, _stream())
+                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
+        if layout is not None and layout[0] > 0:
+            bn_out.append(BnPartial(partial, int(layout[0]), int(layout[1]), y.data_ptr(), (T, B * Ho * Wo, Cout)))
         ctx.prec = bwd_prec
         ctx.save_for_backward(x, w_ohwi)
         ctx.weight_ref = weight if getattr(weight, "_snn_wt", None) is not None else None  # FlatTrainer's cached w^T
@@ -526,7 +534,7 @@ class _Conv2d(Function):
                 _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
                           W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, ctx.prec, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int) -> None:
@@ -564,7 +572,7 @@ class _ComposedConv1x1(Function):
         _small_gemm(w2m, False, w1m, False, wc, 0)
         y = _out_tensor(dest, T, B, C2, H, W, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
-                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, fwd_prec, _stream())
+                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
         ctx.prec = bwd_prec
         ctx.save_for_backward(x, w1m, w2m, wc)
         ctx.geom = (T, B, Cin, H, W, C2, 1, 1, H, W, 1, 0)
@@ -626,13 +634,31 @@ def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: 
     return y[0] if single else y
 
 
+class BnPartial(NamedTuple):
+    """Statistics partials a forward convolution left for the BatchNorm behind it (``snn_conv2d_fwd`` ``bn_partial``)."""
+    partial: torch.Tensor
+    chunks: int
+    rows_per_chunk: int
+    data_ptr: int          # the tensor they describe
+    dims: Tuple[int, int, int]   # (T, pixels per timestep, channels)
+
+
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0, dest: Optional[Dest] = None,
-           forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
-    """``forward_precision`` / ``backward_precision``: this call's arithmetic (None = the session default)."""
+           forward_precision: Optional[str] = None, backward_precision: Optional[str] = None,
+           bn_stats: bool = False) -> torch.Tensor:
+    """``forward_precision`` / ``backward_precision``: this call's arithmetic (None = the session default).
+
+    ``bn_stats``: the result feeds a train-mode BatchNorm - the kernel also emits that layer's statistics partials
+    (attached to the result as ``_snn_bn_partial``; ``affine_neuron`` picks them up and skips its own pass over y).
+    """
     seq, single = as_sequence(x)
+    bn_out = [] if bn_stats else None
     y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq),
-                      _prec_codes(forward_precision, backward_precision))
-    return y[0] if single else y
+                      _prec_codes(forward_precision, backward_precision), bn_out)
+    y = y[0] if single else y
+    if bn_out:
+        y._snn_bn_partial = bn_out[0]
+    return y
 
 
 # ------------------------------------------------------------------------------------------- norm + neuron
@@ -652,6 +678,9 @@ class SynapseState(NamedTuple):
 
 _SAVES_STEP = (_hip.NEURON_LIF, _hip.NEURON_SLI, _hip.NEURON_SYNAPSE)
 SCAN_SEGMENT_T = 32   # backward scans of longer sequences run in segments of this many steps (None: one launch)
+# BatchNorm statistics from the producing convolution's epilogue when it offers them (SNN_NO_CONV_BN_STATS: tuning
+# aid, the separate snn_bn_stats pass everywhere)
+USE_CONV_BN_STATS = not os.environ.get("SNN_NO_CONV_BN_STATS")
 SCAN_FLAGS = 0   # flags of snn_affine_neuron_bwd; tests set _hip.SCAN_WIDE_ADDRESSING to cover the 64-bit-pointer scan
 
 # Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores
@@ -676,7 +705,7 @@ class _AffineNeuron(Function):
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
-         sync_group) = cfg
+         sync_group, bn_hint) = cfg
         _require_device(y, "norm/neuron input")
         ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
@@ -697,15 +726,21 @@ class _AffineNeuron(Function):
             if use_running:
                 if running_mean is None or running_var is None:
                     raise RuntimeError("BatchNorm in eval mode needs running statistics")
-                _hip.call("snn_bn_stats_finalize", None, T, M, C, g_ptr, b_ptr, eps, momentum,
+                _hip.call("snn_bn_stats_finalize", None, 0, 0, T, M, C, g_ptr, b_ptr, eps, momentum,
                           running_mean.data_ptr(), running_var.data_ptr(), 1, mean.data_ptr(), invstd.data_ptr(),
                           alpha.data_ptr(), beta.data_ptr(), st)
             else:
-                n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
-                partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
-                _hip.call("snn_bn_stats", y.data_ptr(), ldy, T, M, C, partial.data_ptr(), st)
+                if (bn_hint is not None and bn_hint.data_ptr == y.data_ptr() and bn_hint.dims == (T, M, C)
+                        and USE_CONV_BN_STATS):
+                    # the producing convolution summed y and y^2 on the way out (snn_conv2d_fwd bn_partial)
+                    partial, chunks, rpc = bn_hint.partial, bn_hint.chunks, bn_hint.rows_per_chunk
+                else:
+                    n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
+                    partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
+                    chunks = rpc = 0
+                    _hip.call("snn_bn_stats", y.data_ptr(), ldy, T, M, C, partial.data_ptr(), st)
                 if sync_group is None:
-                    _hip.call("snn_bn_stats_finalize", partial.data_ptr(), T, M, C, g_ptr, b_ptr, eps, momentum,
+                    _hip.call("snn_bn_stats_finalize", partial.data_ptr(), chunks, rpc, T, M, C, g_ptr, b_ptr, eps, momentum,
                               _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
                               alpha.data_ptr(), beta.data_ptr(), st)
                 else:
@@ -713,7 +748,7 @@ class _AffineNeuron(Function):
                     import torch.distributed as dist
                     world = dist.get_world_size(sync_group[0])
                     sums = torch.empty((T, C, 2), device=dev, dtype=torch.float64)
-                    _hip.call("snn_bn_stats_reduce", partial.data_ptr(), T, M, C, sums.data_ptr(), st)
+                    _hip.call("snn_bn_stats_reduce", partial.data_ptr(), chunks, rpc, T, M, C, sums.data_ptr(), st)
                     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=sync_group[0])
                     scratch = torch.empty((T * C,), device=dev, dtype=torch.float64)
                     _hip.call("snn_bn_stats_from_sums", sums.data_ptr(), T, M * world, C, g_ptr, b_ptr, eps, momentum,
@@ -910,6 +945,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     or None; ``addend`` (same shape as the output) is a residual shortcut added in the output store.
     Returns ``(out, NeuronState | None)``.
     """
+    bn_hint = getattr(y, "_snn_bn_partial", None)
     seq, single = as_sequence(y)
     if addend is not None:
         acc = _acc_of(addend)
@@ -941,7 +977,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             v0, i0 = state
     sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
-           dest, sync_group)
+           dest, sync_group, bn_hint)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, addend, cfg)
     if neuron == _hip.NEURON_NONE:
         new_state = None

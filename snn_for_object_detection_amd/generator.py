@@ -244,7 +244,12 @@ class BlockGen(nn.Module):
                                             backward_precision=(pre_conv.backward_precision
                                                                 or layer.backward_precision))
                 elif isinstance(layer, HipConv2d):
-                    Y = layer(Y, dest=step_dest)
+                    # a train-mode BatchNorm right behind: the convolution sums y, y^2 for it while storing y
+                    feeds_bn = False
+                    if not last and plan[k + 1][0] == "norm_neuron" and Y.is_cuda:
+                        bn = branch[plan[k + 1][1]]
+                        feeds_bn = bn.training or (bn.running_mean is None and bn.running_var is None)
+                    Y = layer(Y, dest=step_dest, bn_stats=feeds_bn)
                 elif isinstance(layer, (LIFCell, LICell, SLICell, SynapseCell)):
                     Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest)
                 elif flags[idx]:

@@ -66,6 +66,114 @@ def test_conv2d_fwd_bwd(HF, T, B, Cin, H, W, Cout, k, s):
     assert rel_err(wd.grad, wr.grad) < 1e-5
 
 
+BN_EPILOGUE_CASES = [
+    # T, B, Cin, H, W, Cout, k, s, kernel that takes the shape
+    (3, 2, 2, 34, 46, 64, 3, 2, "first"),       # row kernel: one group of blocks per timestep
+    (8, 1, 2, 10, 12, 16, 3, 1, "first"),       # fewer rows per timestep than blocks
+    (3, 2, 32, 21, 27, 32, 3, 1, "direct3"),    # patches never straddle a frame
+    (2, 3, 64, 13, 21, 16, 3, 1, "direct3"),
+    (3, 2, 64, 30, 38, 64, 3, 1, "gather"),     # 2280 rows per step: 128-row tiles straddle the timesteps
+    (5, 1, 64, 19, 23, 128, 3, 2, "gather"),    # 120 output pixels per step < one tile: no partials, plain pass
+    (4, 3, 64, 18, 22, 128, 3, 2, "gather"),    # two channel tiles... 297 rows per step
+    (2, 2, 128, 16, 16, 64, 1, 1, "gather"),    # 512 rows per step = 4 whole tiles: nothing straddles
+    (3, 1, 96, 13, 11, 36, 1, 1, "gather"),     # 36 channels in a 64-wide tile, 143 rows per step
+    (2, 2, 8, 13, 9, 27, 5, 1, "gather"),       # generic loader, Cout not a multiple of 4 (scalar stores)
+]
+
+
+@pytest.mark.parametrize("T,B,Cin,H,W,Cout,k,s,kernel", BN_EPILOGUE_CASES)
+def test_bn_statistics_from_the_conv_epilogue(HF, hip_lib, T, B, Cin, H, W, Cout, k, s, kernel):
+    """snn_conv2d_fwd bn_partial: the partials a convolution leaves for the BatchNorm behind it give the same
+    mean / invstd / running statistics as the separate pass over y.  The MFMA kernels sum in fp64 throughout (only the
+    order differs from snn_bn_stats); the first-layer row kernel sums a thread's <= ceil(Wo / pixel lanes) pixels of
+    one row in fp32 before going to fp64 (stated tolerance 1e-6 on the sums, far inside the convolution's own 5e-7
+    per-element error)."""
+    import ctypes
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(Cin * 7 + Cout + T)
+    dev, st, pad = torch.device("cuda"), torch.cuda.current_stream().cuda_stream, k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    N, M = T * B, B * Ho * Wo
+    x = torch.randn(N, H, W, Cin, device=dev) + 0.5
+    w = torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5
+    y = torch.empty(N, Ho, Wo, Cout, device=dev)
+    n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", N, B, Ho, Wo, Cout)
+    partial = torch.full((n_part,), float("nan"), device=dev, dtype=torch.float64)   # unwritten slots must not be read
+    layout = (ctypes.c_int * 2)()
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
+              s, pad, None, 0, partial.data_ptr(), B, layout, _hip.PREC_FP16X3, st)
+    if M < 128 and kernel == "gather":
+        assert layout[0] == 0   # a 128-row tile would meet more than two timesteps: the caller runs snn_bn_stats
+        return
+    assert layout[0] > 0 and (layout[1] == 128) == (kernel == "gather")
+    assert T * layout[0] * Cout * 2 <= n_part
+    yref = torch.empty_like(y)   # the same convolution without the statistics: identical values
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), yref.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k,
+              k, s, pad, None, 0, None, 0, None, _hip.PREC_FP16X3, st)
+    assert torch.equal(y, yref)
+
+    gamma = torch.rand(Cout, device=dev) + 0.5
+    bias = torch.randn(Cout, device=dev)
+
+    def finalize(part, chunks, rpc):
+        out = [torch.empty(T, Cout, device=dev) for _ in range(4)]
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        _hip.call("snn_bn_stats_finalize", part.data_ptr(), chunks, rpc, T, M, Cout, gamma.data_ptr(), bias.data_ptr(),
+                  1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), 0, *[o.data_ptr() for o in out], st)
+        sums = torch.empty(T, Cout, 2, device=dev, dtype=torch.float64)
+        _hip.call("snn_bn_stats_reduce", part.data_ptr(), chunks, rpc, T, M, Cout, sums.data_ptr(), st)
+        return out + [rm, rv], sums
+
+    got, got_sums = finalize(partial, layout[0], layout[1])
+    part2 = torch.empty(_hip.query("snn_bn_stats_partial_size", T, M, Cout), device=dev, dtype=torch.float64)
+    _hip.call("snn_bn_stats", y.data_ptr(), Cout, T, M, Cout, part2.data_ptr(), st)
+    want, want_sums = finalize(part2, 0, 0)
+    y64 = y.double().view(T, M, Cout)
+    exact = torch.stack([y64.sum(1), (y64 * y64).sum(1)], dim=-1)
+    assert torch.isfinite(got_sums).all()
+    tol = 1e-6 if kernel == "first" else 1e-13
+    assert rel_err(got_sums, exact) < tol and rel_err(want_sums, exact) < 1e-13
+    for g_, w_ in zip(got, want):
+        assert torch.isfinite(g_).all()
+        assert rel_err(g_, w_) < (2e-6 if kernel == "first" else 2e-7)   # fp32 roundings of sums that agree to `tol`
+    # deterministic: the same launch again gives the same bits
+    partial_b = torch.zeros_like(partial)
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
+              s, pad, None, 0, partial_b.data_ptr(), B, layout, _hip.PREC_FP16X3, st)
+    again, again_sums = finalize(partial_b, layout[0], layout[1])
+    assert torch.equal(again_sums, got_sums)
+
+
+def test_conv_feeds_batchnorm_statistics_through_the_modules(HF):
+    """HipConv2d -> HipBatchNorm2d -> LIF in a generated block: with and without the epilogue statistics the outputs
+    and every gradient agree (the statistics agree to fp64 rounding)."""
+    from snn_for_object_detection_amd.generator import BlockGen
+    from snn_for_object_detection_amd.layer_gen import Conv, LIF, Norm
+    torch.manual_seed(5)
+    T, B, C, H, W = 3, 2, 32, 24, 30
+    results = []
+    for use in (True, False):
+        torch.manual_seed(11)
+        blk = BlockGen(C, [Conv(32, 3), Norm(), LIF(), Conv(64, 3, 2), Norm(), LIF()]).cuda()
+        blk.train()
+        x = (torch.rand(T, B, C, H, W, device="cuda") < 0.3).float().requires_grad_()
+        HF.USE_CONV_BN_STATS = use
+        try:
+            y, _ = blk(x)
+            (y * torch.linspace(0.5, 1.5, y.numel(), device="cuda").view_as(y)).sum().backward()
+        finally:
+            HF.USE_CONV_BN_STATS = True
+        results.append((y.detach(), x.grad, [p.grad for p in blk.parameters()],
+                        [b.clone() for b in blk.buffers()]))
+    (ya, ga, pa, ba), (yb, gb, pb, bb) = results
+    assert (ya != yb).float().mean() < 1e-4    # spikes: identical unless a membrane sits on the threshold
+    assert rel_err(ga, gb) < 1e-4
+    for u, v in zip(pa, pb):
+        assert rel_err(u, v) < 1e-4
+    for u, v in zip(ba, bb):
+        assert rel_err(u.float(), v.float()) < 1e-6
+
+
 @pytest.mark.parametrize("neuron", ["LIF", "LI"])
 def test_long_backward_scan_in_segments_equals_one_launch(HF, neuron):
     """Sequences longer than SCAN_SEGMENT_T run their backward scan in segments (the per-(t, c) BatchNorm sums of a
