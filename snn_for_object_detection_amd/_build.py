@@ -37,14 +37,17 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False, stamp: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, stamp: bool = False,
+          clock: bool = False) -> str:
     """``tuning=True`` (``--tuning``): compile the bisecting / tuning environment knobs in (``-DSNN_TUNING``) and write
     ``libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment.
     ``stamp=True`` (``--stamp``): additionally ``-DSNN_STAMP`` (in-kernel cycle stamps of the conv main loop,
-    ``tools/stamp_conv.py``) -> ``libsnn_hip_stamp.so``."""
+    ``tools/stamp_conv.py``) -> ``libsnn_hip_stamp.so``.
+    ``clock=True`` (``--clock``): ``-DSNN_CLOCK`` only (begin / end stamps of the shader and the wall clock per block: the
+    clock the chip holds under the kernel's load, ``tools/clock_conv.py``) -> ``libsnn_hip_clock.so``."""
     hipcc = _hipcc()
-    if tuning or stamp:
-        return _build_tuning(hipcc, verbose, stamp)
+    if tuning or stamp or clock:
+        return _build_tuning(hipcc, verbose, stamp, clock)
     headers = [os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
@@ -71,9 +74,10 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, stam
     return LIB_PATH
 
 
-def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False) -> str:
-    out = os.path.join(HERE, "libsnn_hip_stamp.so" if stamp else "libsnn_hip_tuning.so")
-    cmd = [hipcc, *FLAGS, "-DSNN_TUNING", *(["-DSNN_STAMP"] if stamp else []), "-shared",
+def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False, clock: bool = False) -> str:
+    out = os.path.join(HERE, "libsnn_hip_stamp.so" if stamp else "libsnn_hip_clock.so" if clock else "libsnn_hip_tuning.so")
+    cmd = [hipcc, *FLAGS, "-DSNN_TUNING", *(["-DSNN_STAMP"] if stamp else []), *(["-DSNN_CLOCK"] if clock else []),
+           "-shared",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -84,4 +88,5 @@ def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv, stamp="--stamp" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv, stamp="--stamp" in sys.argv,
+                clock="--clock" in sys.argv))

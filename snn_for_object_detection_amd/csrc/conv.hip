@@ -30,8 +30,10 @@
 #include <stdlib.h>
 #include "snn_common.h"
 
-#ifdef SNN_STAMP
-// tuning aid (scratch builds only): per-phase cycle totals of wave 0 of the first 2048 blocks of the pipelined loop
+#if defined(SNN_STAMP) || defined(SNN_CLOCK)
+// tuning aid (scratch builds only).  -DSNN_CLOCK: shader-clock and 100 MHz wall-clock stamps at the begin and end of
+// every block of k_conv_gather (the in-kernel clock under load, tools/clock_conv.py); -DSNN_STAMP additionally the
+// per-phase cycle totals of wave 0 of the first 2048 blocks of the pipelined loop (tools/stamp_conv.py; costs ~10 %)
 __device__ unsigned long long g_stamps[2048 * 8];
 __device__ unsigned long long g_stamps2[2048 * 4];
 extern "C" int snn_debug_stamps(unsigned long long* out, int n) {
@@ -40,6 +42,8 @@ extern "C" int snn_debug_stamps(unsigned long long* out, int n) {
 extern "C" int snn_debug_stamps2(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * n);
 }
+#endif
+#ifdef SNN_STAMP
 #define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
 #else
 #define STAMP(i) do {} while (0)
@@ -182,8 +186,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
     __bf16* Bm = Bl + BN * LDB;
 
     const int tid = threadIdx.x;
-#ifdef SNN_STAMP
-    const unsigned long long st_kernel_begin = __builtin_readcyclecounter();
+#if defined(SNN_STAMP) || defined(SNN_CLOCK)
+    const unsigned long long st_kernel_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_real_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     const int lane_id = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -784,14 +789,12 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         }
         __syncthreads();
     }
-#ifdef SNN_STAMP
+#if defined(SNN_STAMP) || defined(SNN_CLOCK)
     if (tid == 0 && bid_n == 0 && blockIdx.x < 2048) {
         g_stamps2[blockIdx.x * 4 + 0] = st_kernel_begin;
-        g_stamps2[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g_stamps2[blockIdx.x * 4 + 2] = xcc;
-        g_stamps2[blockIdx.x * 4 + 3] = hwid;
+        g_stamps2[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        g_stamps2[blockIdx.x * 4 + 2] = st_real_begin;
+        g_stamps2[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
