@@ -268,9 +268,11 @@ int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float*
 /* C (+)= op(A) x op(B), row-major fp32, op = transpose when the flag is set: A is [M][K] ([K][M] transposed), B is [K][N]
  * ([N][K] transposed), C is [M][N]; every element is an fmaf chain in k order.  For weight-sized matrices: two 1x1
  * convolutions with nothing between them (the C2f entry, models/tiny_yolo.py:76-82) are composed into one, and
- * their weight gradients are products of the composed gradient with the other factor. */
+ * their weight gradients are products of the composed gradient with the other factor.
+ * Ct (may be NULL; accumulate must be 0): the transposed result [N][M] from the same launch - the composed weight and
+ * the operand of its data gradient. */
 int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
-                   int64_t ldc, int M, int N, int K, int accumulate, void* stream);
+                  int64_t ldc, int M, int N, int K, int accumulate, float* Ct, int64_t ldct, void* stream);
 
 /* ConvLSTM cell (conv_lstm.py:51-78), pointwise part after the 1x1 gate convolution.  gates is dense
  * [M][4C] = (input, forget, output, candidate); c_prev NULL = zero state.

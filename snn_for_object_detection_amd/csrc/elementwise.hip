@@ -338,7 +338,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ B, int64_t ldb,
                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                         int accumulate) {
+                                                         int accumulate, float* __restrict__ Ct, int64_t ldct) {
     __shared__ float As[GEMM_KC][33], Bs[GEMM_KC][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict
             if (m < M && n < N) {
                 float* c = C + (int64_t)m * ldc + n;
                 *c = accumulate ? *c + acc[i][j] : acc[i][j];
+                if (Ct) Ct[(int64_t)n * ldct + m] = acc[i][j];   // the transposed copy (weight-sized: strided stores are fine)
             }
         }
 }
@@ -486,16 +487,17 @@ extern "C" int snn_act_bwd(int act, const float* x, const float* y, const float*
 }
 
 extern "C" int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
-                              int64_t ldc, int M, int N, int K, int accumulate, void* stream) {
+                              int64_t ldc, int M, int N, int K, int accumulate, float* Ct, int64_t ldct, void* stream) {
     SNN_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "snn_small_gemm: bad arguments");
     SNN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "snn_small_gemm: leading dimension "
                 "smaller than the row length");
+    SNN_REQUIRE(!Ct || (ldct >= M && !accumulate), "snn_small_gemm: the transposed copy needs ldct >= M and accumulate == 0");
     dim3 grid((unsigned)snn_ceil_div(N, 32), (unsigned)snn_ceil_div(M, 32));
     hipStream_t st = (hipStream_t)stream;
-    if (transA && transB) hipLaunchKernelGGL((k_small_gemm<true, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
-    else if (transA) hipLaunchKernelGGL((k_small_gemm<true, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
-    else if (transB) hipLaunchKernelGGL((k_small_gemm<false, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
-    else hipLaunchKernelGGL((k_small_gemm<false, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate);
+    if (transA && transB) hipLaunchKernelGGL((k_small_gemm<true, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
+    else if (transA) hipLaunchKernelGGL((k_small_gemm<true, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
+    else if (transB) hipLaunchKernelGGL((k_small_gemm<false, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
+    else hipLaunchKernelGGL((k_small_gemm<false, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
     SNN_CHECK_LAUNCH("snn_small_gemm");
     return 0;
 }

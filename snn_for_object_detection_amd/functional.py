@@ -537,12 +537,14 @@ class _Conv2d(Function):
         return dx, dw, None, None, None, None, None, None, None
 
 
-def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int) -> None:
-    """``c (+)= op(a) @ op(b)`` on dense row-major fp32 matrices (``snn_small_gemm``, current stream)."""
+def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int,
+                ct: Optional[torch.Tensor] = None) -> None:
+    """``c (+)= op(a) @ op(b)`` on dense row-major fp32 matrices (``snn_small_gemm``, current stream); ``ct``
+    (``[n, m]``): the transposed result from the same launch."""
     m, n = c.shape
     k = a.shape[0] if trans_a else a.shape[1]
     _hip.call("snn_small_gemm", a.data_ptr(), a.shape[1], int(trans_a), b.data_ptr(), b.shape[1], int(trans_b),
-              c.data_ptr(), n, m, n, k, int(accumulate), _stream())
+              c.data_ptr(), n, m, n, k, int(accumulate), _ptr(ct), m if ct is not None else 0, _stream())
 
 
 class _ComposedConv1x1(Function):
@@ -569,12 +571,16 @@ class _ComposedConv1x1(Function):
         if not (w1m.is_contiguous() and w2m.is_contiguous()):
             w1m, w2m = w1m.contiguous(), w2m.contiguous()
         wc = torch.empty((C2, Cin), device=x.device, dtype=_F32)   # w2 w1: [C2, Cin] = OHWI of a 1x1 kernel
-        _small_gemm(w2m, False, w1m, False, wc, 0)
+        # ... and (w2 w1)^T, the operand of the data gradient, out of the same launch (same fmaf chains: the bits a
+        # separate w1^T w2^T product would give)
+        wct = torch.empty((Cin, C2), device=x.device, dtype=_F32) if ctx.needs_input_grad[0] else None
+        _small_gemm(w2m, False, w1m, False, wc, 0, ct=wct)
         y = _out_tensor(dest, T, B, C2, H, W, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
                   Cin, H, W, C2, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
         ctx.prec = bwd_prec
         ctx.save_for_backward(x, w1m, w2m, wc)
+        ctx.wct = wct
         ctx.geom = (T, B, Cin, H, W, C2, 1, 1, H, W, 1, 0)
         ctx.c1 = C1
         ctx.slots = (slot1, slot2)
@@ -591,8 +597,7 @@ class _ComposedConv1x1(Function):
         st = _stream()
         dx = dw1 = dw2 = None
         if ctx.needs_input_grad[0]:
-            wct = torch.empty((Cin, C2), device=x.device, dtype=_F32)   # (w2 w1)^T = w1^T w2^T: transposed 1x1 weight
-            _small_gemm(w1m, True, w2m, True, wct, 0)
+            wct = ctx.wct   # (w2 w1)^T = w1^T w2^T: transposed 1x1 weight, left by the forward pass
             dx = _dgrad_accumulate(ctx.acc, gy, ldg, wct, x, ctx.geom, st, ctx.prec)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             slot1, slot2 = ctx.slots

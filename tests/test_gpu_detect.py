@@ -179,7 +179,14 @@ def test_small_gemm_matches_torch(hip_lib):
             am = a.t().contiguous() if ta else a
             bm = b.t().contiguous() if tb else b
             c = torch.full((M, N), float("nan"), device="cuda")
-            HF._small_gemm(am, ta, bm, tb, c, 0)
+            ct = torch.full((N, M), float("nan"), device="cuda")
+            HF._small_gemm(am, ta, bm, tb, c, 0, ct=ct)
             assert rel_err(c, want) < 1e-6, (M, N, K, ta, tb)
+            assert torch.equal(ct, c.t())   # the transposed copy of the same launch
+            # ... which is, bit for bit, what the transposed product computes (same fmaf chains: the composed 1x1
+            # convolution takes the operand of its data gradient from the forward launch)
+            ct2 = torch.empty_like(ct)
+            HF._small_gemm(bm, not tb, am, not ta, ct2, 0)
+            assert torch.equal(ct2, ct)
             HF._small_gemm(am, ta, bm, tb, c, 1)
             assert rel_err(c, 2 * want) < 1e-6
