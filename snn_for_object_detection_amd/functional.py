@@ -120,6 +120,8 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # pass stayed reserved at once (257 GiB reserved for 113 GiB live on the 1280x720 B=4 step, and an allocator that
 # frees and re-mallocs its cache each step from B=6 on).  Released this way the blocks are recycled in stream order.
 _SIDE_PENDING = collections.deque()   # (event recorded on the side stream, tensors its kernels read)
+# weight-gradient launches the side stream may lag behind the main stream before the main stream waits for the oldest
+WGRAD_SIDE_DEPTH = int(os.environ.get("SNN_WGRAD_SIDE_DEPTH", "1"))
 
 
 def _side_retire(main, keep: int) -> None:
@@ -515,7 +517,7 @@ class _Conv2d(Function):
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
-                _side_retire(main, 1)   # the weight gradient before the previous one is joined; its operands go
+                _side_retire(main, WGRAD_SIDE_DEPTH)   # the weight gradient before the previous one is joined; its operands go
                 side.wait_stream(main)  # gy (and every earlier use of the slot) is complete
                 with torch.cuda.stream(side):
                     ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
@@ -607,7 +609,7 @@ class _ComposedConv1x1(Function):
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main
             if side_ok:
-                _side_retire(main, 1)
+                _side_retire(main, WGRAD_SIDE_DEPTH)
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 ws = torch.empty((splitk, C2 * Cin), device=x.device, dtype=_F32)

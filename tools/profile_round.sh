@@ -12,7 +12,6 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 B="--config $cfg --no-cpu-baseline"
-python bench.py --config $cfg --kernel-table > $out/bench.json 2> $out/kernel_table.txt || exit 1
 export SNN_NO_WGRAD_STREAM=1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o s -- \
     python3 bench.py $B --steps 5 --warmup 2 --no-roofline > $out/stats1_bench.json 2> $out/stats1.err || exit 1
@@ -26,6 +25,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -o w -- \
     python3 bench.py $P > /dev/null 2> $out/w.err || exit 1
 python tools/pmc_traffic.py $(find $out/pmc_f -name 'f_counter_collection.csv') $(find $out/pmc_w -name 'w_counter_collection.csv') $out/traffic.json > $out/traffic.txt
+# the bench line of this round quotes THESE passes: put the file where bench.py looks for it (tools/collect_profiles.sh
+# copies the same file to the same place in the repository afterwards)
+cp $out/traffic.json profiles/r02_pmc_traffic_$cfg.json
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d $out/pmc_a -o a -- python3 bench.py $P > /dev/null 2> $out/a.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
@@ -34,6 +36,8 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACC
     --output-format csv -d $out/pmc_c -o c -- python3 bench.py $P > /dev/null 2> $out/c.err || exit 1
 python tools/pmc_mfma.py $out/mfma.json $(find $out/pmc_a -name 'a_counter_collection.csv') \
     $(find $out/pmc_b -name 'b_counter_collection.csv') $(find $out/pmc_c -name 'c_counter_collection.csv') > $out/mfma.txt
+unset SNN_NO_WGRAD_STREAM
+python bench.py --config $cfg --kernel-table > $out/bench.json 2> $out/kernel_table.txt || exit 1
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
 ls -R $out | head -60
