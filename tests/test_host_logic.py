@@ -72,6 +72,33 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.snn_affine_neuron_bwd_sums_size(32, 5 * 120 * 152, 64) > 0
 
 
+def test_ctypes_signatures_agree_with_the_header():
+    """Every prototype of include/snn_hip.h, parameter by parameter, against the ctypes signature the product calls it
+    with (a missing or mistyped argument would otherwise hand the kernels garbage without any error)."""
+    from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+    from snn_for_object_detection_amd import _hip
+    header = open(os.path.join(os.path.dirname(_hip._HERE), "include", "snn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|const char\s*\*)\s+(snn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(protos) == len(_hip.SIGNATURES), (len(protos), len(_hip.SIGNATURES))
+
+    def ctype_of(decl):
+        decl = decl.strip()
+        if "*" in decl:
+            return POINTER(_hip.NeuronParams) if "snn_neuron_params" in decl else c_void_p
+        base = decl.rsplit(None, 1)[0].replace("const ", "").strip()   # drop the parameter name
+        return {"int": c_int, "int64_t": c_int64, "float": c_float, "double": c_double, "size_t": c_size_t}[base]
+
+    for ret, name, params in protos:
+        restype, argtypes = _hip.SIGNATURES[name]
+        want_ret = {"int": c_int, "size_t": c_size_t}.get(ret, c_char_p)
+        assert restype is want_ret, (name, restype, want_ret)
+        decls = [] if params.strip() in ("", "void") else params.split(",")
+        assert len(decls) == len(argtypes), (name, len(decls), len(argtypes))
+        for k, (d, a) in enumerate(zip(decls, argtypes)):
+            assert ctype_of(d) is a, (name, k, d.strip(), a)
+
+
 def test_neuron_constants_match_oracle():
     from oracle.neurons import neuron_constants
     p = S.functional.neuron_params()
