@@ -11,6 +11,7 @@ fused Adamax) and must reproduce the 2-rank CPU restatement of the reference's D
 Both ranks share the one GPU of the test box and exchange through gloo (fresh child processes; nothing is re-exec'd
 after the GPU was initialised); the production transport is RCCL, which needs one GPU per rank.
 """
+import datetime
 import os
 import socket
 
@@ -37,7 +38,7 @@ def _shard(rank):
 
 def _worker(rank, world, port, out_dir, sync_bn):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         import snn_for_object_detection_amd as S
         from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters, convert_sync_batchnorm

@@ -2,6 +2,7 @@
 reproduce the single-process full-batch result of the fused Norm+LIF block (outputs, input gradients; the sum
 of the rank-local weight gradients equals the full-batch weight gradient).  Both ranks share the one GPU of the
 test box and exchange through gloo - the production transport is RCCL."""
+import datetime
 import os
 import socket
 
@@ -26,7 +27,7 @@ def _cfg():
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         import snn_for_object_detection_amd as S
         from snn_for_object_detection_amd.trainer import convert_sync_batchnorm
