@@ -291,6 +291,15 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
     frames_per_s = world * B * T * steps / elapsed
+    replicas_equal = None
+    if world > 1:
+        # evidence that the gradient exchange kept the replicas together: after `warmup + steps` updates every rank
+        # holds the same weights (ranks saw different shards, so a missing or partial all-reduce would show here)
+        chk = trainer.flat_param.double().abs().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_equal = bool((lo == hi).item())
     peak_gib = torch.cuda.max_memory_allocated() / 2**30
 
     roofline = None
@@ -388,7 +397,8 @@ def main():
                 "peak_hbm_gib": peak_gib,
             },
             "dist": {"backend": backend, "world_size": world,
-                     "gradient_exchange": "one SUM all-reduce of the flat fp32 gradient per step" if world > 1 else None},
+                     "gradient_exchange": "one SUM all-reduce of the flat fp32 gradient per step" if world > 1 else None,
+                     "replicas_equal_after_run": replicas_equal},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
