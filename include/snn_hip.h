@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 6
+#define SNN_ABI_VERSION 7
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -103,6 +103,12 @@ int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, in
 /* the same for every conv weight of a flat parameter buffer in ONE launch: table[l] = {element offset, Cout, KH*KW, Cin}
  * (device memory, int64); flat_wt mirrors the offsets of flat_w */
 int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int64_t* table, int n_layers, void* stream);
+/* Pre-split weight image for the convolution kernels: every group of 4 consecutive floats of `w` (n floats, n % 4 == 0,
+ * both buffers 16-byte aligned, `out` as large as `w`) becomes 4 high + 4 low 16-bit pieces - fp16 pieces of w * 2^8 for
+ * SNN_PREC_FP16X3 (forward, apply to the OHWI weights), bf16 pieces for SNN_PREC_BF16X3 (data gradient, apply to the
+ * transposed weights) - exactly the pieces the kernels would derive themselves.  Elementwise, so ONE call over a flat
+ * parameter buffer serves every layer whose weight rows start on a multiple of 4 floats; redo after an optimiser step. */
+int snn_weight_presplit(const float* w, void* out, int64_t n, int precision, void* stream);
 
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d(bias=False, padding=int(k/2), stride=s) of layer_gen.py:129-136
@@ -126,16 +132,20 @@ int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int6
  *   second pass over y.  The N frames are T = N / frames_per_step timesteps of frames_per_step frames; bn_partial
  *   holds snn_conv2d_fwd_bn_partial_size() doubles; on return (host side, no synchronisation) bn_layout[0] =
  *   chunks per timestep and bn_layout[1] = rows per chunk, the two layout arguments of snn_bn_stats_finalize /
- *   snn_bn_stats_reduce.  bn_layout[0] == 0: this shape's kernel did not produce them - run snn_bn_stats. */
+ *   snn_bn_stats_reduce.  bn_layout[0] == 0: this shape's kernel did not produce them - run snn_bn_stats.
+ * fwd `w_split` / dgrad `wt_split` (may be NULL): the pre-split image of the same weights (snn_weight_presplit below),
+ *   valid for SNN_PREC_FP16X3 (fwd) / SNN_PREC_BF16X3 (dgrad) only.  With it the kernels stop converting the weight
+ *   tile in every block; the results are bit-identical to the conversion on the fly.  Shapes whose kernel cannot use
+ *   it read `w` / `wt` as before, so both pointers are always passed. */
 size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step, int Ho, int Wo, int Cout);
-int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy,
+int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const void* w_split, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                    int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend,
                    double* bn_partial, int frames_per_step, int* bn_layout, int precision, void* stream);
 /* dgrad takes TWO optional addends (dx = conv^T(dy) + addend + addend2): a tensor consumed by a convolution, a
  * residual shortcut and a Dense pass-through (the YOLO bottleneck inside a C2f block) gets its whole gradient in one
  * epilogue instead of two extra add passes. */
-int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx,
+int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, const void* wt_split, float* dx, int64_t lddx,
                      int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                      int KH, int KW, int stride, int pad, const float* addend, int64_t ld_addend,
                      const float* addend2, int64_t ld_addend2, int precision, void* stream);

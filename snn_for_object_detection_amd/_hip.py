@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1 = 0, 1, 3, 4, 5   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING = 1
 
@@ -38,10 +38,11 @@ SIGNATURES = {
     "snn_weight_transpose_batched": (c_int, [_P, _P, _P, _I, _P]),
     "snn_detect_decode": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "snn_nms_sorted": (c_int, [_P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
-    "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _I,
+    "snn_conv2d_fwd": (c_int, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _I, _P, _I,
                                _P]),
+    "snn_weight_presplit": (c_int, [_P, _P, _L, _I, _P]),
     "snn_conv2d_fwd_bn_partial_size": (c_size_t, [_L, _I, _I, _I, _I]),
-    "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L,
+    "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L,
                                  _I, _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P]),

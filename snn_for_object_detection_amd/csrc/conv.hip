@@ -161,8 +161,12 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // offset".  Loads are raw buffer loads relative to the block's first image; padding / out-of-range rows get the
 // offset 0xFFFFFFFF and the hardware range check returns zeros - no clamps, no value selects, no 64-bit address
 // arithmetic in the loop (the generic loader spends more VALU cycles on addresses than the MFMAs take).
-template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST>
-__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
+// PRESPLIT (FAST, SPLIT 2 or 4 only): `wk` is not the fp32 weight matrix but its pre-split image (snn_weight_presplit:
+// per 4 consecutive k, 4 hi pieces then 4 lo pieces - the same 16 bytes at the same offsets), written once per optimiser
+// step; the loader is unchanged and the per-block conversion of the weight tile (half of the conversion VALU of a
+// k-step, repeated by every one of the ~1 400 blocks of a launch) disappears.  Same bits as converting on the fly.
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false>
+__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add,
                                                           const float* __restrict__ addend2, int64_t ld_add2) {
@@ -482,6 +486,15 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
                 out[1][e] = p[0]; out[1][e + 1] = p[1];
             }
         };
+        auto convert_b = [&](const f32x4& v, bf16x4* out) {
+            if constexpr (PRESPLIT) {   // the 16 bytes already are (4 hi, 4 lo)
+                static_assert(!PRESPLIT || SPLIT == 2 || SPLIT == 4, "pre-split weights: two-piece modes only");
+                out[0] = __builtin_bit_cast(bf16x4, f32x2{v[0], v[1]});
+                out[1] = __builtin_bit_cast(bf16x4, f32x2{v[2], v[3]});
+            } else {
+                convert(v, out, kF16WeightScale);
+            }
+        };
         auto write_tiles = [&]() {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -543,7 +556,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
         constexpr int NM = TM * TN * NPROD;              // MFMAs per k16 group
         constexpr int NREAD = (TM + TN) * NP;            // ds_read_b128 per k16 group
         constexpr int CONV_OPS = SPLIT == 3 ? 24 : (SPLIT == 5 ? 2 : 14);   // VALU per converted f32x4 (approx.)
-        constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM, VPG_B = (BROWS * CONV_OPS + NM - 1) / NM;
+        constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM;
+        constexpr int VPG_B = PRESPLIT ? 1 : (BROWS * CONV_OPS + NM - 1) / NM;   // pre-split: only register moves
         if (g.Ktot > 0) {
             // both first tiles are requested back to back (the accumulators are not live yet, registers are free):
             // one exposed memory latency per block instead of two
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
 #pragma unroll
             for (int j = 0; j < 4; ++j) convert(ra0[j], pa[j], kF16ActScale);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) convert(rb0[j], pb[j], kF16WeightScale);
+            for (int j = 0; j < BROWS; ++j) convert_b(rb0[j], pb[j]);
             write_tiles();
         }
         __syncthreads();
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? 2 : SNN_CONV_MIN_WAVES)
             STAMP(0);
             mfma_group(1);
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) convert(rb[j], pb[j], kF16WeightScale);
+            for (int j = 0; j < BROWS; ++j) convert_b(rb[j], pb[j]);
             __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -1350,8 +1364,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_reduce4(const float* __restr
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <bool DGRAD, int SPLIT>
-static int launch_gather(const float* in, const float* wk, float* out, const ConvGeom& g, const float* addend,
-                         int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st, const char* name) {
+static int launch_gather(const float* in, const float* wk, const void* wk_split, float* out, const ConvGeom& g,
+                         const float* addend, int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st,
+                         const char* name) {
     const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(g.Mtot < 0x7fffffffLL && (int64_t)g.IH * g.IW < 0x7fffffffLL, "%s: too many pixels", name);
@@ -1363,6 +1378,8 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
     ConvGeom gg = g;
     gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
                  (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
+    // the pre-split weight image serves the pipelined kernel in its two-piece modes; every other path converts wk itself
+    const bool presplit = wk_split != nullptr && (SPLIT == 2 || SPLIT == 4) && aligned16(wk_split);
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
     do {                                                                                                    \
         gg.mtiles = (int)gm;                                                                                \
@@ -1370,7 +1387,12 @@ static int launch_gather(const float* in, const float* wk, float* out, const Con
         gg.ntiles = (int)snn_ceil_div(g.OC, BN_);                                                           \
         SNN_REQUIRE((int64_t)gg.mtiles_per_xcd * 8 * gg.ntiles <= 0x7fffffffLL, "%s: grid too large", name); \
         dim3 grid((unsigned)(gg.mtiles_per_xcd * 8 * gg.ntiles));                                           \
-        if (fast)                                                                                           \
+        if (fast && presplit) {                                                                             \
+            if constexpr (SPLIT == 2 || SPLIT == 4)                                                         \
+                hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true, true>), grid,    \
+                                   dim3(kThreads), 0, st, in, static_cast<const float*>(wk_split), out, gg, addend, \
+                                   ld_add, addend2, ld_add2);                                               \
+        } else if (fast)                                                                                    \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true>), grid, dim3(kThreads), 0, \
                                st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);                                        \
         else if (vec)                                                                                       \
@@ -2005,6 +2027,59 @@ static int first_layer_blocks(int64_t rows) {  // grid of the row-walking kernel
 }
 }  // namespace
 
+// ---- pre-split weight images (see PRESPLIT of k_conv_gather).  Elementwise over groups of 4 consecutive floats: the
+// group's 16 bytes become (4 hi pieces, 4 lo pieces) with exactly the arithmetic of the in-kernel conversion - fp16
+// pieces of w * 2^8 (forward, SNN_PREC_FP16X3) or bf16 pieces of w (data gradient, SNN_PREC_BF16X3; apply it to the
+// transposed weights).  A weight row (KH*KW*Cin floats) must start on a group boundary.
+namespace {
+template <bool F16>
+__global__ void k_weight_presplit(const f32x4* __restrict__ w, u32x4* __restrict__ out, int64_t groups) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = w[i];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (F16) {
+                const float a = v[e] * kF16WeightScale, b = v[e + 1] * kF16WeightScale;
+                const f16x2 ph = __builtin_convertvector(f32x2{a, b}, f16x2);
+                const f16x2 pl = __builtin_convertvector(f32x2{a - (float)ph[0], b - (float)ph[1]}, f16x2);
+                o[e >> 1] = __builtin_bit_cast(unsigned, ph);
+                o[2 + (e >> 1)] = __builtin_bit_cast(unsigned, pl);
+            } else {
+                f32x2 rest = {v[e], v[e + 1]};
+                const bf16x2 ph = __builtin_convertvector(rest, bf16x2);
+                const unsigned bits = __builtin_bit_cast(unsigned, ph);
+                rest[0] -= __builtin_bit_cast(float, bits << 16);
+                rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+                const bf16x2 pl = __builtin_convertvector(rest, bf16x2);
+                o[e >> 1] = bits;
+                o[2 + (e >> 1)] = __builtin_bit_cast(unsigned, pl);
+            }
+        }
+        out[i] = o;
+    }
+}
+}  // namespace
+
+extern "C" int snn_weight_presplit(const float* w, void* out, int64_t n, int precision, void* stream) {
+    SNN_REQUIRE(w && out && n > 0 && n % 4 == 0, "snn_weight_presplit: bad arguments (n = %lld must be a multiple of 4)",
+                (long long)n);
+    SNN_REQUIRE(aligned16(w) && aligned16(out), "snn_weight_presplit: buffers must be 16-byte aligned");
+    SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3,
+                "snn_weight_presplit: precision must be SNN_PREC_FP16X3 (forward) or SNN_PREC_BF16X3 (data gradient)");
+    const int64_t groups = n / 4;
+    int64_t blocks = snn_ceil_div(groups, kThreads);
+    if (blocks > 8 * snn_num_cu()) blocks = 8 * snn_num_cu();
+    if (precision == SNN_PREC_FP16X3)
+        hipLaunchKernelGGL(k_weight_presplit<true>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f32x4*>(w), reinterpret_cast<u32x4*>(out), groups);
+    else
+        hipLaunchKernelGGL(k_weight_presplit<false>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f32x4*>(w), reinterpret_cast<u32x4*>(out), groups);
+    SNN_CHECK_LAUNCH("snn_weight_presplit");
+    return 0;
+}
+
 // Chunk slots per timestep of the three forward kernels' statistics partials (see stat_flush); 0: not produced.
 namespace {
 struct FirstGroups { int rows, blocks; };
@@ -2032,11 +2107,13 @@ extern "C" size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step,
     return (size_t)(T * chunks * Cout * 2);
 }
 
-extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t N, int H,
-                              int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                              const float* addend, int64_t ld_addend, double* bn_partial, int frames_per_step,
+extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const void* w_split, float* y, int64_t ldy,
+                              int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                              int pad, const float* addend, int64_t ld_addend, double* bn_partial, int frames_per_step,
                               int* bn_layout, int precision, void* stream) {
     SNN_REQUIRE(x && w && y, "snn_conv2d_fwd: null pointer");
+    SNN_REQUIRE(!w_split || precision == SNN_PREC_FP16X3,
+                "snn_conv2d_fwd: a pre-split weight image exists for SNN_PREC_FP16X3 only (precision %d)", precision);
     SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3 ||
                     precision == SNN_PREC_BF16X1,
                 "snn_conv2d_fwd: precision must be SNN_PREC_FP32, _BF16X6, _FP16X3 or _BF16X1 (got %d)", precision);
@@ -2101,19 +2178,21 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, float
         bn_layout[1] = BM;
     }
     if (fwd_split == 5)
-        return launch_gather<false, 5>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+        return launch_gather<false, 5>(x, w, nullptr, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 4)
-        return launch_gather<false, 4>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+        return launch_gather<false, 4>(x, w, w_split, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 3)
-        return launch_gather<false, 3>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
-    return launch_gather<false, 0>(x, w, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+        return launch_gather<false, 3>(x, w, nullptr, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
+    return launch_gather<false, 0>(x, w, nullptr, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
 }
 
-extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, float* dx, int64_t lddx, int64_t N,
-                                int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                                const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2,
-                                int precision, void* stream) {
+extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, const void* wt_split, float* dx,
+                                int64_t lddx, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                int stride, int pad, const float* addend, int64_t ld_addend, const float* addend2,
+                                int64_t ld_addend2, int precision, void* stream) {
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
+    SNN_REQUIRE(!wt_split || precision == SNN_PREC_BF16X3,
+                "snn_conv2d_dgrad: a pre-split weight image exists for SNN_PREC_BF16X3 only (precision %d)", precision);
     SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1,
                 "snn_conv2d_dgrad: precision must be SNN_PREC_FP32, SNN_PREC_BF16X3 or SNN_PREC_BF16X1 (got %d)", precision);
     const int bwd_split = precision;
@@ -2151,11 +2230,11 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
             int rc = bwd_split == SNN_PREC_BF16X1
-                         ? launch_gather<true, 5>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                         ? launch_gather<true, 5>(dy, wt, nullptr, dx, g, addend, ld_addend, addend2, ld_addend2,
                                                   (hipStream_t)stream, "snn_conv2d_dgrad")
-                         : (split ? launch_gather<true, 2>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                         : (split ? launch_gather<true, 2>(dy, wt, wt_split, dx, g, addend, ld_addend, addend2, ld_addend2,
                                                            (hipStream_t)stream, "snn_conv2d_dgrad")
-                                  : launch_gather<true, 0>(dy, wt, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                  : launch_gather<true, 0>(dy, wt, nullptr, dx, g, addend, ld_addend, addend2, ld_addend2,
                                                            (hipStream_t)stream, "snn_conv2d_dgrad"));
             if (rc) return rc;
         }

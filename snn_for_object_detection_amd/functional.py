@@ -411,7 +411,7 @@ def _slot_of(param) -> Optional[GradSlot]:
 
 
 # ------------------------------------------------------------------------------------------- conv
-def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec):
+def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None):
     """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
     (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
     T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
@@ -444,7 +444,7 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec):
         prev = acc[0].result
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
-    _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin,
+    _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), wt_split, dx.data_ptr(), Cin, T * B, H, W, Cin,
               Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
     if acc is not None and (acc[0].result is None or chained):
         if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
@@ -483,8 +483,14 @@ class _Conv2d(Function):
             n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", T * B, B, Ho, Wo, Cout)
             partial = torch.empty((n_part,), device=x.device, dtype=torch.float64)
             layout = (ctypes.c_int * 2)()
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
-                  H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
+        # FlatTrainer keeps a pre-split image of the weights (valid while the version counter matches): ready-made pieces
+        w16 = None
+        if (fwd_prec == _hip.PREC_FP16X3 and USE_PRESPLIT_WEIGHTS and w_ohwi is w
+                and getattr(weight, "_snn_w16_ptr", None) is not None and weight._snn_wt_version == weight._version):
+            w16 = weight._snn_w16_ptr
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), w16, y.data_ptr(), cl_stride(y),
+                  T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec,
+                  _stream())
         if layout is not None and layout[0] > 0:
             bn_out.append(BnPartial(partial, int(layout[0]), int(layout[1]), y.data_ptr(), (T, B * Ho * Wo, Cout)))
         ctx.prec = bwd_prec
@@ -505,12 +511,15 @@ class _Conv2d(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wref = ctx.weight_ref
+            wt16 = None
             if wref is not None and wref._snn_wt_version == wref._version:
                 wt = wref._snn_wt  # transposed once per optimiser step for all layers (trainer.FlatTrainer)
+                if ctx.prec == _hip.PREC_BF16X3 and USE_PRESPLIT_WEIGHTS and USE_PRESPLIT_DGRAD:
+                    wt16 = getattr(wref, "_snn_wt16_ptr", None)   # ... and pre-split into its bf16 pieces
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
-            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec)
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
             if ctx.slot is not None and USE_WGRAD_STREAM:
@@ -578,8 +587,8 @@ class _ComposedConv1x1(Function):
         wct = torch.empty((Cin, C2), device=x.device, dtype=_F32) if ctx.needs_input_grad[0] else None
         _small_gemm(w2m, False, w1m, False, wc, 0, ct=wct)
         y = _out_tensor(dest, T, B, C2, H, W, x)
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), y.data_ptr(), cl_stride(y), T * B, H, W,
-                  Cin, H, W, C2, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), None, y.data_ptr(), cl_stride(y), T * B,
+                  H, W, Cin, H, W, C2, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
         ctx.prec = bwd_prec
         ctx.save_for_backward(x, w1m, w2m, wc)
         ctx.wct = wct
@@ -688,6 +697,11 @@ SCAN_SEGMENT_T = 32   # backward scans of longer sequences run in segments of th
 # BatchNorm statistics from the producing convolution's epilogue when it offers them (SNN_NO_CONV_BN_STATS: tuning
 # aid, the separate snn_bn_stats pass everywhere)
 USE_CONV_BN_STATS = not os.environ.get("SNN_NO_CONV_BN_STATS")
+# pre-split weight images kept by FlatTrainer (SNN_NO_PRESPLIT_WEIGHTS: tuning aid, conversion in every block)
+USE_PRESPLIT_WEIGHTS = not os.environ.get("SNN_NO_PRESPLIT_WEIGHTS")
+# ... for the data gradient too: measured neutral (its bf16 split is three bit operations per pair, the forward's fp16 split a
+# scale, two conversions and a subtraction), so off by default: one launch and one weight-sized buffer less per step
+USE_PRESPLIT_DGRAD = bool(os.environ.get("SNN_PRESPLIT_DGRAD"))
 SCAN_FLAGS = 0   # flags of snn_affine_neuron_bwd; tests set _hip.SCAN_WIDE_ADDRESSING to cover the 64-bit-pointer scan
 
 # Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores

@@ -43,6 +43,7 @@ def _conv_label(name: str, a) -> str:
 def work_of(name: str, a):
     """-> (label, flops, bytes) for one launch, or (name, 0, 0) for bookkeeping kernels."""
     if name in ("snn_conv2d_fwd", "snn_conv2d_dgrad"):
+        a = tuple(a[:3]) + tuple(a[4:])   # without the pre-split weight pointer: the positions snn_conv2d_wgrad has
         n, h, w, cin, ho, wo, cout, kh, kw = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
         byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)

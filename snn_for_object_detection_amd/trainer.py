@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
+from . import functional as _HF
 from .functional import GradSlot, wgrad_stream_sync
 
 
@@ -62,7 +63,13 @@ class FlatTrainer:
         self.grad_views: List[torch.Tensor] = []
         # transposed copies [Cin][KH][KW][Cout] of every conv weight (operand of the data-gradient conv), refreshed
         # by ONE kernel after each optimiser step instead of one launch per layer inside the backward pass
-        self.flat_wt = torch.empty(total_padded, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        self.flat_wt = torch.zeros(total_padded, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        # pre-split images of both (snn_weight_presplit: fp16 hi/lo pieces of w * 2^8 for the forward convolutions, bf16
+        # hi/lo pieces of w^T for the data gradients), refreshed with the transposes: the convolution kernels then read
+        # ready-made pieces instead of converting the weight tile in every block
+        self.flat_w16 = torch.empty(total_padded, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        self.flat_wt16 = (torch.empty(total_padded, device=dev, dtype=torch.float32)
+                          if dev.type == "cuda" and _HF.USE_PRESPLIT_DGRAD else None)
         self._conv_params: List[torch.nn.Parameter] = []
         table = []
         off = 0
@@ -83,6 +90,11 @@ class FlatTrainer:
                 table.append([off, o, kh * kw, i])
                 p._snn_wt = self.flat_wt[off:off + p.numel()].view(i, kh, kw, o)
                 p._snn_wt_version = -1  # not valid yet
+                # rows of both matrices must start on a 4-float group of the flat buffers
+                if off % 4 == 0 and (kh * kw * i) % 4 == 0 and (kh * kw * o) % 4 == 0:
+                    p._snn_w16_ptr = self.flat_w16.data_ptr() + 4 * off
+                    if self.flat_wt16 is not None:
+                        p._snn_wt16_ptr = self.flat_wt16.data_ptr() + 4 * off
                 self._conv_params.append(p)
             off += p.numel()
         self._wt_table = torch.tensor(table, dtype=torch.int64, device=dev) if table else None
@@ -106,8 +118,13 @@ class FlatTrainer:
         torch-side in-place update simply falls back to the per-layer transpose until the next call."""
         if self._wt_table is None:
             return
+        st = torch.cuda.current_stream().cuda_stream
         _hip.call("snn_weight_transpose_batched", self.flat_param.data_ptr(), self.flat_wt.data_ptr(),
-                  self._wt_table.data_ptr(), len(self._conv_params), torch.cuda.current_stream().cuda_stream)
+                  self._wt_table.data_ptr(), len(self._conv_params), st)
+        n = self.flat_param.numel()
+        _hip.call("snn_weight_presplit", self.flat_param.data_ptr(), self.flat_w16.data_ptr(), n, _hip.PREC_FP16X3, st)
+        if self.flat_wt16 is not None:
+            _hip.call("snn_weight_presplit", self.flat_wt.data_ptr(), self.flat_wt16.data_ptr(), n, _hip.PREC_BF16X3, st)
         for p in self._conv_params:
             p._snn_wt_version = p._version
 

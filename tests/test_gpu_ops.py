@@ -100,7 +100,7 @@ def test_bn_statistics_from_the_conv_epilogue(HF, hip_lib, T, B, Cin, H, W, Cout
     n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", N, B, Ho, Wo, Cout)
     partial = torch.full((n_part,), float("nan"), device=dev, dtype=torch.float64)   # unwritten slots must not be read
     layout = (ctypes.c_int * 2)()
-    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
               s, pad, None, 0, partial.data_ptr(), B, layout, _hip.PREC_FP16X3, st)
     if M < 128 and kernel == "gather":
         assert layout[0] == 0   # a 128-row tile would meet more than two timesteps: the caller runs snn_bn_stats
@@ -108,7 +108,7 @@ def test_bn_statistics_from_the_conv_epilogue(HF, hip_lib, T, B, Cin, H, W, Cout
     assert layout[0] > 0 and (layout[1] == 128) == (kernel == "gather")
     assert T * layout[0] * Cout * 2 <= n_part
     yref = torch.empty_like(y)   # the same convolution without the statistics: identical values
-    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), yref.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k,
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), None, yref.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k,
               k, s, pad, None, 0, None, 0, None, _hip.PREC_FP16X3, st)
     assert torch.equal(y, yref)
 
@@ -138,10 +138,85 @@ def test_bn_statistics_from_the_conv_epilogue(HF, hip_lib, T, B, Cin, H, W, Cout
         assert rel_err(g_, w_) < (2e-6 if kernel == "first" else 2e-7)   # fp32 roundings of sums that agree to `tol`
     # deterministic: the same launch again gives the same bits
     partial_b = torch.zeros_like(partial)
-    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
+    _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k,
               s, pad, None, 0, partial_b.data_ptr(), B, layout, _hip.PREC_FP16X3, st)
     again, again_sums = finalize(partial_b, layout[0], layout[1])
     assert torch.equal(again_sums, got_sums)
+
+
+PRESPLIT_CASES = [
+    # N, Cin, H, W, Cout, k, s
+    (6, 128, 30, 38, 128, 3, 1),   # pipelined kernel, 128-wide tile
+    (4, 64, 33, 41, 64, 3, 1),     # 64-wide tile
+    (3, 64, 31, 45, 128, 3, 2),    # stride 2: four phase classes in the data gradient
+    (5, 128, 20, 24, 64, 1, 1),    # 1x1
+    (2, 96, 9, 11, 36, 1, 1),      # 36 channels in a 64-wide tile (rows past Cout read offset -1)
+    (2, 32, 12, 19, 32, 3, 1),     # halo-resident direct kernel: ignores the image
+    (2, 8, 13, 9, 16, 5, 1),       # generic loader: ignores the image
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s", PRESPLIT_CASES)
+def test_presplit_weight_images_give_the_same_bits(HF, hip_lib, N, Cin, H, W, Cout, k, s):
+    """snn_weight_presplit + the w_split / wt_split arguments: forward and data gradient with ready-made weight pieces
+    equal the conversion on the fly bit for bit (the image holds exactly the pieces the kernels derive themselves)."""
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(N * 100 + Cin + Cout + k)
+    dev, st, pad = torch.device("cuda"), torch.cuda.current_stream().cuda_stream, k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, W, Cin, device=dev)
+    w = torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5
+    w[0, 0, 0, :4] = torch.tensor([3e-6, -1e-7, 200.0, 0.0], device=dev)   # tiny, subnormal-piece and large weights
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    dy = torch.randn(N, Ho, Wo, Cout, device=dev)
+    w16, wt16 = torch.empty_like(w), torch.empty_like(wt)
+    _hip.call("snn_weight_presplit", w.data_ptr(), w16.data_ptr(), w.numel(), _hip.PREC_FP16X3, st)
+    _hip.call("snn_weight_presplit", wt.data_ptr(), wt16.data_ptr(), wt.numel(), _hip.PREC_BF16X3, st)
+    ys, dxs = [], []
+    for a, b in ((None, None), (w16.data_ptr(), wt16.data_ptr())):
+        y, dx = torch.empty(N, Ho, Wo, Cout, device=dev), torch.empty(N, H, W, Cin, device=dev)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), a, y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k,
+                  k, s, pad, None, 0, None, 0, None, _hip.PREC_FP16X3, st)
+        _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), b, dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo,
+                  Cout, k, k, s, pad, None, 0, None, 0, _hip.PREC_BF16X3, st)
+        ys.append(y)
+        dxs.append(dx)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(dxs[0], dxs[1])
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), stride=s, padding=pad)
+    assert rel_err(ys[1].permute(0, 3, 1, 2), ref) < 2e-6
+    with pytest.raises(RuntimeError, match="pre-split"):   # an image is tied to its arithmetic
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), w16.data_ptr(), ys[0].data_ptr(), Cout, N, H, W, Cin,
+                  Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, None, _hip.PREC_BF16X6, st)
+
+
+def test_flat_trainer_presplit_weights_leave_the_step_bit_identical(HF):
+    """The training step of a generated block with FlatTrainer's pre-split weight images and without: identical loss,
+    gradients and updated weights, and the images follow the weights through optimiser steps."""
+    from snn_for_object_detection_amd.generator import BlockGen
+    from snn_for_object_detection_amd.layer_gen import Conv, LIF, Norm
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    outs = []
+    for use in (True, False):
+        torch.manual_seed(3)
+        blk = BlockGen(32, [Conv(64, 3), Norm(), LIF(), Conv(128, 3, 2), Norm(), LIF(), Conv(64, 1)]).cuda().train()
+        tr = FlatTrainer(blk, lr=1e-2)
+        x = (torch.rand(4, 2, 32, 24, 30, device="cuda") < 0.3).float()
+        HF.USE_PRESPLIT_WEIGHTS = use
+        try:
+            losses = []
+            for _ in range(3):
+                tr.zero_grad()
+                y, _ = blk(x)
+                loss = (y * y).mean()
+                loss.backward()
+                tr.step()
+                losses.append(loss.item())
+            tr.synchronize()
+        finally:
+            HF.USE_PRESPLIT_WEIGHTS = True
+        outs.append((losses, tr.flat_grad.clone(), tr.flat_param.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
 def test_conv_feeds_batchnorm_statistics_through_the_modules(HF):
@@ -281,7 +356,7 @@ def test_dgrad_two_fused_addends(HF, hip_lib):
         a1, a2 = wide1[..., 4:4 + Cin], wide2[..., Cin:]
         plain = torch.empty(N, H, W, Cin, device="cuda")
         fused = torch.empty_like(plain)
-        args = (dy.data_ptr(), Cout, wt.data_ptr())
+        args = (dy.data_ptr(), Cout, wt.data_ptr(), None)
         geom = (N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad)
         prec = _hip.PREC_BF16X3   # the arithmetic is an argument of every call (ABI v5)
         _hip.call("snn_conv2d_dgrad", *args, plain.data_ptr(), Cin, *geom, None, 0, None, 0, prec, st)

@@ -24,9 +24,9 @@ dy = torch.randn(N, Ho, Wo, Cout, device=dev)
 dx = torch.empty_like(x)
 for _ in range(3):
     if op == "fwd":
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, None, 4, st)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, None, 4, st)
     else:
-        _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, 1, st)
+        _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), None, dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, None, 0, None, 0, 1, st)
 torch.cuda.synchronize()
 nblk = min(2048, (N * (H if op == "dgrad" else Ho) * (W if op == "dgrad" else Wo) + 127) // 128)
 nblk = nblk // 8 * 8  # XCD-aware order: the last ids may be padding blocks
