@@ -65,9 +65,13 @@ enum {
  * The mode is an argument of every call - the library keeps no process-wide arithmetic state. */
 enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4, SNN_PREC_BF16X1 = 5 };
 
-/* flags of snn_affine_neuron_bwd */
-enum { SNN_SCAN_WIDE_ADDRESSING = 1 /* use 64-bit pointer addressing even when one timestep of every tensor fits the
-                                       31-bit buffer offsets (the library switches by itself when it does not) */ };
+/* flags of snn_affine_neuron_fwd / _bwd */
+enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even when one timestep of every tensor fits
+                                        the 31-bit buffer offsets (the library switches by itself when it does not) */
+       SNN_SCAN_LAST_STEP_ONLY = 2   /* LI / LI+Tanh whose consumer keeps the last timestep only (the detection head,
+                                        soda.py:141-144): fwd writes out[M][ldo] of step T-1 instead of [T][M][ldo];
+                                        bwd takes g_out[M][ldg] (and, LI+Tanh, the saved output [M][C]) of that step,
+                                        the output gradient of every earlier step being zero */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
@@ -210,7 +214,7 @@ int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
                           const float* v0, const float* i0,
                           float* out, int64_t ldo, const float* addend, int64_t ld_addend,
                           float* vT, float* iT, float* vdec,
-                          int T, int64_t M, int C, const snn_neuron_params* p, void* stream);
+                          int T, int64_t M, int C, const snn_neuron_params* p, int flags, void* stream);
 
 /* Reverse-time scan (BPTT through the neuron, SuperSpike surrogate dz/du = 1/(alpha|u|+1)^2,
  * reset path NOT detached).  g_out is dL/d out[t]; g_vT/g_iT (may be NULL = 0) are the
@@ -220,7 +224,7 @@ int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
  * `state` is the forward's vdec buffer for LIF / SLI / SYNAPSE, out (tanh output) for LI_TANH, unused otherwise.
  * alpha/beta (may be NULL = identity): the forward's affine, needed to rebuild x[t] for SLI / SYNAPSE.
  * apply_scale != 0: gx is multiplied by alpha[t,c] before it is written (eval-mode BN: dy = alpha*gx).
- * flags: 0 or SNN_SCAN_WIDE_ADDRESSING. */
+ * flags: 0, SNN_SCAN_WIDE_ADDRESSING, SNN_SCAN_LAST_STEP_ONLY (or both). */
 size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C);
 int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state,
                           const float* y, int64_t ldy, const float* g_vT, const float* g_iT,

@@ -17,7 +17,7 @@ POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 7
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1 = 0, 1, 3, 4, 5   # SNN_PREC_* of include/snn_hip.h
-SCAN_WIDE_ADDRESSING = 1
+SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY = 1, 2
 
 
 class NeuronParams(Structure):
@@ -55,7 +55,7 @@ SIGNATURES = {
     "snn_bn_bwd_reduce": (c_int, [_P, _I, _L, _I, _P, _P]),
     "snn_bn_bwd_coef": (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_affine_neuron_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I,
-                                      POINTER(NeuronParams), _P]),
+                                      POINTER(NeuronParams), _I, _P]),
     "snn_lif_ckpt_interval": (c_int, []),
     "snn_lif_fwd_ckpt": (c_int, [_P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I,
                                  POINTER(NeuronParams), _P]),

@@ -286,7 +286,9 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     const float* __restrict__ y, int64_t ldy, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ v0, const float* __restrict__ i0, float* __restrict__ out, int64_t ldo,
     const float* __restrict__ addend, int64_t ld_add, float* __restrict__ vT, float* __restrict__ iT,
-    float* __restrict__ vdec, int T, int64_t M, int C, snn_neuron_params p) {
+    float* __restrict__ vdec, int T, int64_t M, int C, snn_neuron_params p, int last_only) {
+    // last_only (SNN_SCAN_LAST_STEP_ONLY): `out` is [M][ldo], only the last timestep's output is kept (the detection
+    // head: soda.py:141-144 returns the predictions of the last step) - T-1 of T output stores never happen
     typedef typename Vec<VEC>::type V;
     const int cv = C / VEC;
     const int64_t total = M * cv;
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(ad, j);
             }
-            Vec<VEC>::store(out + row * ldo + c, o);
+            if (!last_only) Vec<VEC>::store(out + row * ldo + c, o);
+            else if (t == T - 1) Vec<VEC>::store(out + m * ldo + c, o);
             if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
                 Vec<VEC>::store(vdec + row * C + c, vd);
         }
@@ -452,7 +455,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
     const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
-    float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p) {
+    float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p,
+    int last_only) {
+    // last_only (SNN_SCAN_LAST_STEP_ONLY; LI / LI+Tanh): g_out and the saved output are [M][..] tensors of the LAST
+    // timestep; the output gradient of every earlier step is zero and nothing is read for it
     typedef typename Vec<VEC>::type V;
     constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
     constexpr bool kNeedsState = (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH || kNeedsX);
@@ -506,14 +512,19 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)t * M * ld), 0, (int)(M * ld * 4),
                                                      0x00020000);
         };
+        auto slab_out = [&](const float* base, int t, int64_t ld) {  // g_out / saved output: all steps, or the last one only
+            if (!last_only) return slab(base, t, ld);
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, t == T - 1 ? (int)(M * ld * 4) : 0,
+                                                     0x00020000);   // zero records: every load returns 0
+        };
         auto fetch = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
             if constexpr (BUF) {
-                const __amdgpu_buffer_rsrc_t rg = slab(g_out, t, ldg);
+                const __amdgpu_buffer_rsrc_t rg = slab_out(g_out, t, ldg);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
                     go[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rg, og[q], 0, 0));
                 if (kNeedsState) {
-                    const __amdgpu_buffer_rsrc_t rs = slab(state, t, C);
+                    const __amdgpu_buffer_rsrc_t rs = (NEURON == SNN_NEURON_LI_TANH) ? slab_out(state, t, C) : slab(state, t, C);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
                         st[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, os[q], 0, 0));
@@ -529,8 +540,15 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 for (int q = 0; q < NP; ++q) {
                     if (ok[q]) {
                         const int64_t row = (int64_t)t * M + mq[q];
-                        go[q] = Vec<VEC>::load(g_out + row * ldg + c);
-                        if (kNeedsState) st[q] = Vec<VEC>::load(state + row * C + c);
+                        const int64_t row_o = last_only ? mq[q] : row;
+                        const bool live = !last_only || t == T - 1;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) lane<VEC>(go[q], j) = lane<VEC>(st[q], j) = 0.0f;
+                        if (live) go[q] = Vec<VEC>::load(g_out + row_o * ldg + c);
+                        if (kNeedsState) {
+                            if (NEURON != SNN_NEURON_LI_TANH) st[q] = Vec<VEC>::load(state + row * C + c);
+                            else if (live) st[q] = Vec<VEC>::load(state + row_o * C + c);
+                        }
                         if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
                     }
                 }
@@ -1157,17 +1175,21 @@ extern "C" int snn_bn_stats_from_sums(const double* sums, int T, int64_t M_total
     do {                                                                                                          \
         if (vec == 4)                                                                                             \
             hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 4, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
-                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p); \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p, last_only); \
         else                                                                                                      \
             hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 1, SAVE>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
-                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p); \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p, last_only); \
     } while (0)
 
 static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta, const float* v0,
                       const float* i0, float* out, int64_t ldo, const float* addend, int64_t ld_addend, float* vT,
                       float* iT, float* vdec, int ckpt_mode, int T, int64_t M, int C, const snn_neuron_params* p,
-                      void* stream) {
+                      int flags, void* stream) {
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
+    SNN_REQUIRE((flags & ~SNN_SCAN_LAST_STEP_ONLY) == 0, "snn_affine_neuron_fwd: unknown flags 0x%x", flags);
+    const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
+    SNN_REQUIRE(!last_only || ((neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH) && !addend),
+                "snn_affine_neuron_fwd: SNN_SCAN_LAST_STEP_ONLY is for LI / LI+Tanh without a shortcut");
     SNN_REQUIRE(!addend || (ld_addend >= C && neuron != SNN_NEURON_LI_TANH),
                 "snn_affine_neuron_fwd: addend needs ld_addend >= C and is not allowed with LI_TANH");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && ldo >= C, "snn_affine_neuron_fwd: bad shape");
@@ -1210,9 +1232,9 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
 extern "C" int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alpha, const float* beta,
                                      const float* v0, const float* i0, float* out, int64_t ldo, const float* addend,
                                      int64_t ld_addend, float* vT, float* iT, float* vdec, int T, int64_t M, int C,
-                                     const snn_neuron_params* p, void* stream) {
+                                     const snn_neuron_params* p, int flags, void* stream) {
     return neuron_fwd(neuron, y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, 0, T, M, C, p,
-                      stream);
+                      flags, stream);
 }
 
 extern "C" int snn_lif_ckpt_interval(void) { return kCkpt; }
@@ -1223,7 +1245,7 @@ extern "C" int snn_lif_fwd_ckpt(const float* y, int64_t ldy, const float* alpha,
                                 void* stream) {
     SNN_REQUIRE(ckpt, "snn_lif_fwd_ckpt: null checkpoint buffer");
     return neuron_fwd(SNN_NEURON_LIF, y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, ckpt, 1, T, M,
-                      C, p, stream);
+                      C, p, 0, stream);
 }
 
 extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
@@ -1235,7 +1257,7 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
 #define SNN_LAUNCH_BWD_(NEURON, VEC_, MODE_, BUF_, NP_)                                                          \
     hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, VEC_, MODE_, BUF_, NP_>), grid, dim3(kThreads), pl.lds_bytes, \
                        (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, \
-                       g_v0, g_i0, sums, T, M, C, pl.cvb, *p)
+                       g_v0, g_i0, sums, T, M, C, pl.cvb, *p, last_only)
 #define SNN_LAUNCH_BWD(NEURON, VEC_, MODE_)                                             \
     do {                                                                                \
         if (VEC_ == 4 && buf_ok && pl.rpb == 1) SNN_LAUNCH_BWD_(NEURON, 4, MODE_, true, 1); \
@@ -1261,7 +1283,11 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
                                      double* sums, int T, int64_t M, int C, const snn_neuron_params* p,
                                      int flags, void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
-    SNN_REQUIRE((flags & ~SNN_SCAN_WIDE_ADDRESSING) == 0, "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
+    SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY)) == 0,
+                "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
+    const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
+    SNN_REQUIRE(!last_only || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH,
+                "snn_affine_neuron_bwd: SNN_SCAN_LAST_STEP_ONLY is for LI / LI+Tanh");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
     SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_bwd: bad neuron %d",
                 neuron);

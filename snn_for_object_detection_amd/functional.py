@@ -726,7 +726,7 @@ class _AffineNeuron(Function):
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
-         sync_group, bn_hint) = cfg
+         sync_group, bn_hint, last_only) = cfg
         _require_device(y, "norm/neuron input")
         ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
@@ -775,7 +775,13 @@ class _AffineNeuron(Function):
                     _hip.call("snn_bn_stats_from_sums", sums.data_ptr(), T, M * world, C, g_ptr, b_ptr, eps, momentum,
                               _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
                               alpha.data_ptr(), beta.data_ptr(), scratch.data_ptr(), st)
-        out = _out_tensor(dest, T, B, C, H, W, y)
+        if last_only:
+            # only the last timestep's output is kept (snn_affine_neuron_fwd SNN_SCAN_LAST_STEP_ONLY): out is [B,C,H,W]
+            if neuron not in (_hip.NEURON_LI, _hip.NEURON_LI_TANH) or addend is not None or dest is not None:
+                raise RuntimeError("last_only is for LI / LI+Tanh without shortcut or concat destination")
+            out = _new_cl((B,), C, H, W, y)
+        else:
+            out = _out_tensor(dest, T, B, C, H, W, y)
         has_state = neuron != _hip.NEURON_NONE
         vT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
         iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
@@ -811,8 +817,10 @@ class _AffineNeuron(Function):
         else:
             _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
                       out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
-                      _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params, st)
+                      _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params,
+                      _hip.SCAN_LAST_STEP_ONLY if last_only else 0, st)
         ctx.ckpt = ckpt
+        ctx.last_only = last_only
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
         ctx.sync_group = sync_group if (has_bn and not use_running) else None
@@ -841,9 +849,10 @@ class _AffineNeuron(Function):
             if ctx.addend_acc is not None:  # lets the shortcut's producer-side dgrad add it in its epilogue
                 ctx.addend_acc[0].deposit(ctx.addend_acc[1], g_out)
         if g_out is None:
-            g_out = torch.zeros((T, B, H, W, C), device=dev, dtype=_F32)
+            g_out = torch.zeros((B, H, W, C) if ctx.last_only else (T, B, H, W, C), device=dev, dtype=_F32)
             g_out = _cl_view(g_out)
         g_out = _raw_to_cl(g_out)
+        scan_flags = SCAN_FLAGS | (_hip.SCAN_LAST_STEP_ONLY if ctx.last_only else 0)
         ldg, ldy = cl_stride(g_out), cl_stride(y)
         if not has_state:
             g_vT = g_iT = None
@@ -889,7 +898,7 @@ class _AffineNeuron(Function):
         # block only, i.e. 64-byte runs per pixel - measured 2.6 TB/s against 4.6 at T = 32.  The recurrence crosses a
         # segment boundary through (g_v, g_i), which the kernel already takes and returns: same values bit for bit.
         segmented = (need_sums and has_state and not ctx.ckpt and ctx.sync_group is None and SCAN_SEGMENT_T
-                     and T > SCAN_SEGMENT_T)
+                     and T > SCAN_SEGMENT_T and not ctx.last_only)
         if segmented:
             fr_g, fr_y, fr_c = M * ldg * 4, M * ldy * 4, M * C * 4    # bytes per timestep of g_out / y / dense tensors
             gv_in, gi_in = g_vT, g_iT
@@ -919,7 +928,7 @@ class _AffineNeuron(Function):
         else:
             _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), y.data_ptr(), ldy,
                       _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0),
-                      _ptr(g_i0), _ptr(sums), T, M, C, params, SCAN_FLAGS, st)
+                      _ptr(g_i0), _ptr(sums), T, M, C, params, scan_flags, st)
         if need_sums:
             if segmented:
                 pass   # coefficients and parameter gradients were finalised per segment
@@ -959,11 +968,13 @@ def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
 
 def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = None, bn=None,
                   params: Optional[NeuronParams] = None, dest: Optional[Dest] = None,
-                  addend: Optional[torch.Tensor] = None):
+                  addend: Optional[torch.Tensor] = None, last_only: bool = False):
     """Fused ``[Norm] -> [neuron] [+ addend]`` over a sequence or a single step.
 
     ``bn`` is an ``nn.BatchNorm2d``-like module (weight, bias, running stats, eps, momentum, training)
     or None; ``addend`` (same shape as the output) is a residual shortcut added in the output store.
+    ``last_only`` (LI / LI+Tanh on a sequence): return the output of the LAST timestep only, ``[B,C,H,W]`` - the other
+    T-1 outputs are never written and the backward pass reads no output gradient for them.
     Returns ``(out, NeuronState | None)``.
     """
     bn_hint = getattr(y, "_snn_bn_partial", None)
@@ -998,7 +1009,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             v0, i0 = state
     sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
-           dest, sync_group, bn_hint)
+           dest, sync_group, bn_hint, bool(last_only) and not single)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, addend, cfg)
     if neuron == _hip.NEURON_NONE:
         new_state = None
@@ -1006,6 +1017,8 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
         new_state = SynapseState(vT)
     else:
         new_state = NeuronState(vT, iT)
+    if last_only and not single:
+        return out, new_state
     return (out[0] if single else out), new_state
 
 

@@ -175,8 +175,12 @@ class BlockGen(nn.Module):
         return True
 
     # ------------------------------------------------------------------ execution
-    def forward(self, X: torch.Tensor, state: Optional[ListState] = None, dest=None, promise=None, pre_conv=None):
+    def forward(self, X: torch.Tensor, state: Optional[ListState] = None, dest=None, promise=None, pre_conv=None,
+                last_only: bool = False):
         """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence).
+
+        ``last_only`` (internal; the detection head): the caller keeps the last timestep only - when the block ends in
+        ``Norm -> LI [-> Tanh]`` the fused scan returns ``[B,C,h,w]`` of the last step and never writes the others.
 
         ``dest`` / ``promise`` are internal (``functional.Dest`` / ``ConcatPromise``): on sequences the
         Dense merge is zero-copy - each branch's last operator writes its channel slice of one shared
@@ -227,8 +231,11 @@ class BlockGen(nn.Module):
                     shortcut = None
                     if fuse_here and last:  # the block's merged output: LIF(...) + shortcut, placed at `dest`
                         direct, shortcut = dest, inputs[self._fused_shortcut[1]]
+                    only_last = (last_only and last and zero_copy and len(self.net) == 1 and direct is None
+                                 and shortcut is None and neuron in (_hip.NEURON_LI, _hip.NEURON_LI_TANH)
+                                 and not (isinstance(holder, StateStorage) and not self.training))
                     Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct,
-                                              addend=shortcut)
+                                              addend=shortcut, last_only=only_last)
                     if isinstance(holder, StateStorage):
                         holder.record(old, Y, new)
                     branch_state[idx + 1] = new
@@ -237,7 +244,8 @@ class BlockGen(nn.Module):
                     Y, branch_state[idx + 1] = blk(Y, branch_state[idx + 1], dest=step_dest, promise=step_promise,
                                                    pre_conv=layer)
                 elif isinstance(layer, BlockGen):
-                    Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise)
+                    Y, branch_state[idx] = layer(Y, branch_state[idx], dest=step_dest, promise=step_promise,
+                                                 last_only=last_only and last and len(self.net) == 1)
                 elif isinstance(layer, HipConv2d) and pre_conv is not None and k == 0:
                     Y = HF.composed_conv1x1(Y, pre_conv.weight, layer.weight, dest=step_dest,
                                             forward_precision=pre_conv.forward_precision or layer.forward_precision,
@@ -416,10 +424,11 @@ class HeadGen(ModelGen):
 
     def forward(self, X: torch.Tensor, state: Optional[ListState]):
         state = [None] * 3 if state is None else state
-        Y, state[0] = self.base_net(X, state[0])
-        if Y.dim() == 5 and not (any(_has_state(m) for m in self.box_net.modules())
-                                 or any(_has_state(m) for m in self.cls_net.modules())):
-            # sequence input, stateless prediction nets: only the last timestep's predictions survive
+        # sequence input, stateless prediction nets: only the last timestep's predictions survive
+        keep_last = X.dim() == 5 and not (any(_has_state(m) for m in self.box_net.modules())
+                                          or any(_has_state(m) for m in self.cls_net.modules()))
+        Y, state[0] = self.base_net(X, state[0], last_only=keep_last)
+        if Y.dim() == 5 and keep_last:
             Y = Y[-1]
         box, state[1] = self.box_net(Y, state[1])
         cls, state[2] = self.cls_net(Y, state[2])

@@ -571,6 +571,36 @@ def test_bn_li_tanh_fused_and_eval_mode(HF):
         assert rel_err(bnd.bias.grad, bn.bias.grad) < 2e-5
 
 
+@pytest.mark.parametrize("tanh", [True, False])
+def test_last_step_only_scan_equals_the_full_scan(HF, tanh):
+    """SNN_SCAN_LAST_STEP_ONLY (the detection head keeps the last timestep only): the [B,C,H,W] output equals the last
+    step of the full scan, and every gradient equals the one the full scan gets from an output gradient that is zero
+    before the last step - bit for bit."""
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(17)
+    T, B, C, H, W = 6, 3, 64, 9, 11
+    neuron = _hip.NEURON_LI_TANH if tanh else _hip.NEURON_LI
+    x = torch.randn(T, B, C, H, W, device="cuda")
+    g_last = torch.randn(B, C, H, W, device="cuda")
+    res = []
+    for last_only in (True, False):
+        torch.manual_seed(1)
+        bn = HipBatchNorm2d(C).cuda().train()
+        bn.weight.data.uniform_(0.5, 1.5)
+        xin = x.clone().requires_grad_()
+        out, st = HF.affine_neuron(xin, neuron, None, bn=bn, last_only=last_only)
+        if last_only:
+            assert out.shape == (B, C, H, W)
+            out.backward(g_last)
+        else:
+            out[-1].backward(g_last)
+            out = out[-1]
+        res.append((out.detach(), xin.grad, bn.weight.grad, st.v.detach(), bn.running_mean.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_lif_state_carry_equals_sequence(HF):
     """T single-step calls with carried state (reference protocol) == one sequence call, bitwise; and
     gradients flow through the carried state (time-outer BPTT)."""

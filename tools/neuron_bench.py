@@ -28,11 +28,11 @@ for (T, B, H, W, C) in [(32, 5, 120, 152, 64), (32, 5, 120, 152, 32), (32, 5, 60
 
     def fwd():
         _hip.call("snn_affine_neuron_fwd", 1, y.data_ptr(), C, alpha.data_ptr(), beta.data_ptr(), None, None,
-                  out.data_ptr(), C, None, 0, vT.data_ptr(), iT.data_ptr(), vdec.data_ptr(), T, M, C, p, st)
+                  out.data_ptr(), C, None, 0, vT.data_ptr(), iT.data_ptr(), vdec.data_ptr(), T, M, C, p, 0, st)
 
     def bwd(with_sums):
         _hip.call("snn_affine_neuron_bwd", 1, go.data_ptr(), C, vdec.data_ptr(), y.data_ptr(), C, None, None, None, None,
-                  0, gx.data_ptr(), None, None, sums.data_ptr() if with_sums else None, T, M, C, p, st)
+                  0, gx.data_ptr(), None, None, sums.data_ptr() if with_sums else None, T, M, C, p, 0, st)
 
     for name, fn, tensors in (("fwd", fwd, 3), ("bwd nosum", lambda: bwd(False), 3), ("bwd sums", lambda: bwd(True), 4)):
         for _ in range(2):
