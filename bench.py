@@ -247,8 +247,9 @@ def main():
         probe = deep12_probe(B, H, W, device)
 
         def loss_fn():
-            out, _ = model(X)
-            return (out[-1] * probe).mean()
+            # the loss reads the spikes of the last timestep only (as the detector does, models/soda.py:141-144)
+            out, _ = model(X, last_only=True)
+            return (out * probe).mean()
         lr = 1e-3
     else:
         model = S.TinyYolo(num_classes=classes, time_window=0).to(device).train()

@@ -68,7 +68,7 @@ enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP1
 /* flags of snn_affine_neuron_fwd / _bwd */
 enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even when one timestep of every tensor fits
                                         the 31-bit buffer offsets (the library switches by itself when it does not) */
-       SNN_SCAN_LAST_STEP_ONLY = 2   /* LI / LI+Tanh whose consumer keeps the last timestep only (the detection head,
+       SNN_SCAN_LAST_STEP_ONLY = 2   /* LIF / LI / LI+Tanh whose consumer keeps the last timestep only (the detection head,
                                         soda.py:141-144): fwd writes out[M][ldo] of step T-1 instead of [T][M][ldo];
                                         bwd takes g_out[M][ldg] (and, LI+Tanh, the saved output [M][C]) of that step,
                                         the output gradient of every earlier step being zero */ };

@@ -457,8 +457,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
     float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p,
     int last_only) {
-    // last_only (SNN_SCAN_LAST_STEP_ONLY; LI / LI+Tanh): g_out and the saved output are [M][..] tensors of the LAST
-    // timestep; the output gradient of every earlier step is zero and nothing is read for it
+    // last_only (SNN_SCAN_LAST_STEP_ONLY; LIF / LI / LI+Tanh): g_out (and LI+Tanh's saved output) are [M][..] tensors of
+    // the LAST timestep; the output gradient of every earlier step is zero and nothing is read for it
     typedef typename Vec<VEC>::type V;
     constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
     constexpr bool kNeedsState = (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH || kNeedsX);
@@ -1188,8 +1188,9 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
     SNN_REQUIRE((flags & ~SNN_SCAN_LAST_STEP_ONLY) == 0, "snn_affine_neuron_fwd: unknown flags 0x%x", flags);
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
-    SNN_REQUIRE(!last_only || ((neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH) && !addend),
-                "snn_affine_neuron_fwd: SNN_SCAN_LAST_STEP_ONLY is for LI / LI+Tanh without a shortcut");
+    SNN_REQUIRE(!last_only || ((neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH) &&
+                               !addend),
+                "snn_affine_neuron_fwd: SNN_SCAN_LAST_STEP_ONLY is for LIF / LI / LI+Tanh without a shortcut");
     SNN_REQUIRE(!addend || (ld_addend >= C && neuron != SNN_NEURON_LI_TANH),
                 "snn_affine_neuron_fwd: addend needs ld_addend >= C and is not allowed with LI_TANH");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && ldo >= C, "snn_affine_neuron_fwd: bad shape");
@@ -1286,8 +1287,8 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY)) == 0,
                 "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
-    SNN_REQUIRE(!last_only || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH,
-                "snn_affine_neuron_bwd: SNN_SCAN_LAST_STEP_ONLY is for LI / LI+Tanh");
+    SNN_REQUIRE(!last_only || neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH,
+                "snn_affine_neuron_bwd: SNN_SCAN_LAST_STEP_ONLY is for LIF / LI / LI+Tanh");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
     SNN_REQUIRE(neuron >= SNN_NEURON_NONE && neuron <= SNN_NEURON_SYNAPSE, "snn_affine_neuron_bwd: bad neuron %d",
                 neuron);

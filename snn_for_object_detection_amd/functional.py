@@ -777,8 +777,9 @@ class _AffineNeuron(Function):
                               alpha.data_ptr(), beta.data_ptr(), scratch.data_ptr(), st)
         if last_only:
             # only the last timestep's output is kept (snn_affine_neuron_fwd SNN_SCAN_LAST_STEP_ONLY): out is [B,C,H,W]
-            if neuron not in (_hip.NEURON_LI, _hip.NEURON_LI_TANH) or addend is not None or dest is not None:
-                raise RuntimeError("last_only is for LI / LI+Tanh without shortcut or concat destination")
+            if (neuron not in (_hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH) or addend is not None
+                    or dest is not None):
+                raise RuntimeError("last_only is for LIF / LI / LI+Tanh without shortcut or concat destination")
             out = _new_cl((B,), C, H, W, y)
         else:
             out = _out_tensor(dest, T, B, C, H, W, y)
@@ -898,11 +899,12 @@ class _AffineNeuron(Function):
         # block only, i.e. 64-byte runs per pixel - measured 2.6 TB/s against 4.6 at T = 32.  The recurrence crosses a
         # segment boundary through (g_v, g_i), which the kernel already takes and returns: same values bit for bit.
         segmented = (need_sums and has_state and not ctx.ckpt and ctx.sync_group is None and SCAN_SEGMENT_T
-                     and T > SCAN_SEGMENT_T and not ctx.last_only)
+                     and T > SCAN_SEGMENT_T)
         if segmented:
             fr_g, fr_y, fr_c = M * ldg * 4, M * ldy * 4, M * C * 4    # bytes per timestep of g_out / y / dense tensors
             gv_in, gi_in = g_vT, g_iT
             first = True
+            g_none = None   # last_only: the output gradient of every segment but the last one is zero
             for t1 in range(T, 0, -SCAN_SEGMENT_T):
                 t0 = max(0, t1 - SCAN_SEGMENT_T)
                 ts = t1 - t0
@@ -912,11 +914,20 @@ class _AffineNeuron(Function):
                 n_sums = _hip.query("snn_affine_neuron_bwd_sums_size", ts, M, C)
                 seg_sums = torch.empty((n_sums,), device=dev, dtype=torch.float64)
                 tc = t0 * C * 4
-                _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr() + t0 * fr_g, ldg,
-                          None if state is None else state.data_ptr() + t0 * fr_c, y.data_ptr() + t0 * fr_y, ldy,
+                if not ctx.last_only:
+                    g_seg = g_out.data_ptr() + t0 * fr_g
+                elif t1 == T:
+                    g_seg = g_out.data_ptr()          # [B,H,W,C] of the last step = the last step of this segment
+                else:
+                    if g_none is None:
+                        g_none = torch.zeros_like(g_out)
+                    g_seg = g_none.data_ptr()
+                st_off = 0 if (ctx.last_only and neuron == _hip.NEURON_LI_TANH) else t0 * fr_c   # saved output: last step only
+                _hip.call("snn_affine_neuron_bwd", neuron, g_seg, ldg,
+                          None if state is None else state.data_ptr() + st_off, y.data_ptr() + t0 * fr_y, ldy,
                           _ptr(gv_in), _ptr(gi_in), None if alpha is None else alpha.data_ptr() + tc,
                           None if beta is None else beta.data_ptr() + tc, apply_scale, gx.data_ptr() + t0 * fr_c,
-                          gv_out.data_ptr(), gi_out.data_ptr(), seg_sums.data_ptr(), ts, M, C, params, SCAN_FLAGS, st)
+                          gv_out.data_ptr(), gi_out.data_ptr(), seg_sums.data_ptr(), ts, M, C, params, scan_flags, st)
                 _hip.call("snn_bn_bwd_finalize", seg_sums.data_ptr(), ts, M, C, _ptr(gamma), mean.data_ptr() + tc,
                           invstd.data_ptr() + tc, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
                           coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)

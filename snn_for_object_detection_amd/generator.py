@@ -180,7 +180,7 @@ class BlockGen(nn.Module):
         """``X`` is ``[B,C,h,w]`` (one timestep) or ``[T,B,C,h,w]`` (whole sequence).
 
         ``last_only`` (internal; the detection head): the caller keeps the last timestep only - when the block ends in
-        ``Norm -> LI [-> Tanh]`` the fused scan returns ``[B,C,h,w]`` of the last step and never writes the others.
+        ``Norm -> LIF`` / ``Norm -> LI [-> Tanh]`` the fused scan returns ``[B,C,h,w]`` of the last step and never writes the others.
 
         ``dest`` / ``promise`` are internal (``functional.Dest`` / ``ConcatPromise``): on sequences the
         Dense merge is zero-copy - each branch's last operator writes its channel slice of one shared
@@ -232,7 +232,8 @@ class BlockGen(nn.Module):
                     if fuse_here and last:  # the block's merged output: LIF(...) + shortcut, placed at `dest`
                         direct, shortcut = dest, inputs[self._fused_shortcut[1]]
                     only_last = (last_only and last and zero_copy and len(self.net) == 1 and direct is None
-                                 and shortcut is None and neuron in (_hip.NEURON_LI, _hip.NEURON_LI_TANH)
+                                 and shortcut is None
+                                 and neuron in (_hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH)
                                  and not (isinstance(holder, StateStorage) and not self.training))
                     Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct,
                                               addend=shortcut, last_only=only_last)

@@ -571,6 +571,27 @@ def test_bn_li_tanh_fused_and_eval_mode(HF):
         assert rel_err(bnd.bias.grad, bn.bias.grad) < 2e-5
 
 
+def test_last_step_only_lif_long_sequence_in_segments(HF):
+    """The same for LIF at T = 70 (> SCAN_SEGMENT_T): the backward scan runs in segments, only the last of which has an
+    output gradient."""
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(23)
+    T, B, C, H, W = 70, 2, 32, 7, 9
+    x = torch.randn(T, B, C, H, W, device="cuda") * 2
+    g_last = torch.randn(B, C, H, W, device="cuda")
+    res = []
+    for last_only in (True, False):
+        bn = HipBatchNorm2d(C).cuda().train()
+        xin = x.clone().requires_grad_()
+        out, st = HF.affine_neuron(xin, _hip.NEURON_LIF, None, bn=bn, last_only=last_only)
+        (out if last_only else out[-1]).backward(g_last)
+        res.append(((out if last_only else out[-1]).detach(), xin.grad, bn.weight.grad, st.v.detach(), st.i.detach()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert res[0][0].sum() > 0 and res[0][1].abs().sum() > 0
+
+
 @pytest.mark.parametrize("tanh", [True, False])
 def test_last_step_only_scan_equals_the_full_scan(HF, tanh):
     """SNN_SCAN_LAST_STEP_ONLY (the detection head keeps the last timestep only): the [B,C,H,W] output equals the last
