@@ -35,14 +35,14 @@ def test_config0_gen1_frame_b1_t8_forward_matches_oracle(S):
     assert rel_err(cls, cls_r) < 1e-4 and rel_err(box, box_r) < 1e-4
 
 
-def _train_mode_layerwise(S, T, H, W, classes, p=0.05):
+def _train_mode_layerwise(S, T, H, W, classes, p=0.05, B=1):
     """Forward pass in TRAIN mode (per-timestep batch statistics) on product and oracle with every LIF / LI output
     recorded (the taps are switched to recording although BatchNorm keeps training).  Returns the predictions and,
     per tapped layer in execution order, (name, oracle spikes, mismatching spikes per timestep | LI rel. error)."""
     from oracle.net import StateStorage as RefTap
     from snn_for_object_detection_amd.layer_gen import StateStorage
     product, oracle = make_pair(S.TinyYolo, num_classes=classes, time_window=0, state_storage=True)
-    X = synthetic_events(T, 1, H, W, p=p)
+    X = synthetic_events(T, B, H, W, p=p)
     product.train()
     oracle.train()
     for m in list(product.modules()) + list(oracle.modules()):
@@ -78,6 +78,39 @@ def test_config0_gen1_frame_train_mode_all_layers_match_oracle(S):
     assert mism <= 1e-5 * spikes, (mism, spikes)
     if mism == 0:
         assert rel_err(preds[1], preds_r[1]) < 1e-4 and rel_err(preds[2], preds_r[2]) < 1e-4
+
+
+def test_config1_gen1_b5_t32_forward_matches_oracle_layer_by_layer(S):
+    """BASELINE configs[1] at its FULL size (TinyYolo, GEN1 304x240, B=5, T=32: the workload of the bench line), forward
+    pass in train mode against the oracle - 26 M neurons per step over 32 steps, 845 M neuron-timesteps.
+
+    Measured (`tools/diag_config1.py`): every one of the 19 LIF layers is bit-identical to the oracle for the first four
+    timesteps; the first disagreement anywhere is ONE neuron of a 60x76 layer at t = 4 (a potential within fp32 rounding
+    of the threshold: the product's split-precision convolution and torch's CPU convolution differ by 5e-7), the
+    120x152 entry layer differs in 6 of its 3.29 M spikes, and from there batch statistics and recurrence spread the
+    difference (chaos: a third of the spikes of the smallest maps by t = 32) while every layer's firing rate stays within
+    0.4 % of the oracle's.  Asserted: that structure - exact prefix, single-neuron first event, a near-exact entry
+    layer, firing rates within 1 %.  (The same run with the separate statistics pass instead of the convolution
+    epilogues gives the identical mismatch counts, layer for layer.)"""
+    T = 32
+    preds, preds_r, layers = _train_mode_layerwise(S, T, 240, 304, 2, B=5)
+    assert torch.equal(preds[0].cpu(), preds_r[0]) and preds[0].shape == (13545, 4)
+    lif = [row for row in layers if row[1] is not None]
+    assert len(lif) == 19
+    firsts = [next((t for t, n in enumerate(row[2]) if n > 0), T) for row in lif]
+    t_star = min(firsts)
+    assert t_star >= 3, firsts                       # >= 3 x 26 M neuron-timesteps bit-identical in every layer
+    if t_star < T:
+        k = firsts.index(t_star)                     # the shallowest layer that disagrees at t*
+        assert lif[k][2][t_star] <= 3, (lif[k][0], lif[k][2][t_star])
+    entry = lif[0]
+    assert sum(entry[2]) <= 1e-5 * entry[1], (sum(entry[2]), entry[1])
+    for name, n_ref, per_t, n_prod in lif:
+        assert n_ref > 0 and abs(n_prod - n_ref) <= 0.01 * n_ref, (name, n_ref, n_prod)
+    if t_star == T:
+        assert rel_err(preds[1], preds_r[1]) < 1e-4 and rel_err(preds[2], preds_r[2]) < 1e-4
+    else:
+        assert rel_err(preds[1], preds_r[1]) < 0.3 and rel_err(preds[2], preds_r[2]) < 0.3
 
 
 def test_config3_1mpx_frame_b1_t8_matches_oracle_layer_by_layer(S):
