@@ -70,6 +70,11 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.snn_conv2d_wgrad_splitk(160, 120, 152, 32, 120, 152, 32, 3, 3, 1, 1, _hip.PREC_BF16X3) >= 1
     assert hip_lib.snn_bn_stats_partial_size(32, 5 * 120 * 152, 64) > 0
     assert hip_lib.snn_affine_neuron_bwd_sums_size(32, 5 * 120 * 152, 64) > 0
+    # partials a forward convolution leaves for the BatchNorm behind it: bound over the three producing kernels
+    n = hip_lib.snn_conv2d_fwd_bn_partial_size(160, 5, 120, 152, 64)
+    assert n >= 32 * (5 * 120 * 152 // 128 + 1) * 64 * 2           # >= the implicit-GEMM layout (128-row tiles)
+    assert n >= 32 * 5 * 15 * 10 * 64 * 2                           # >= the 8x16-patch layout of the direct kernel
+    assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 7, 120, 152, 64) == 0   # frames per step must divide N
 
 
 def test_ctypes_signatures_agree_with_the_header():
