@@ -99,7 +99,7 @@ constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS image
 
 // ---- BatchNorm statistics out of a forward epilogue.  The separate pass (snn_bn_stats) re-reads the whole layer
 // output from HBM; the epilogue has every value in registers on its way to the store.  Layout of the partials is the
-// one snn_bn_stats_finalize reads: partial[t][chunk][c][2] = (sum y, sum y^2) in fp64, a chunk being whatever set of
+// one snn_bn_stats_finalize reads: partial[t][c][chunk][2] = (sum y, sum y^2) in fp64, a chunk being whatever set of
 // pixels of timestep t one block (tile) owns.  The MFMA accumulator layout already is "one channel per lane": lane
 // (r, h) of wave (wm, wn) holds channel (wn*TN + j)*32 + r of the 16 rows (wm*TM + i)*32 + (e&3) + 8*(e>>2) + 4*h,
 // so a lane sums its own registers, the two half-waves are added by one shuffle and the WM waves through LDS, in
@@ -108,8 +108,8 @@ constexpr int LDB = BK + 8;  // bf16 row stride of the split-precision LDS image
 //
 // red: 4 * TN * 32 * 2 doubles of LDS, free to use; dst: the [C][2] slot of this block's chunk.  Block-uniform call.
 template <int WM, int WN, int TN>
-__device__ __forceinline__ void stat_flush(double (&s)[TN], double (&q)[TN], double* red, double* __restrict__ dst,
-                                           int n0, int OC, int tid) {
+__device__ __forceinline__ void stat_flush(double (&s)[TN], double (&q)[TN], double* red, double* __restrict__ partial,
+                                           int64_t step, int64_t chunk, int64_t chunks, int n0, int OC, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -131,8 +131,9 @@ __device__ __forceinline__ void stat_flush(double (&s)[TN], double (&q)[TN], dou
             qq += src[1];
         }
         if (n0 + tid < OC) {
-            dst[(int64_t)(n0 + tid) * 2 + 0] = ss;
-            dst[(int64_t)(n0 + tid) * 2 + 1] = qq;
+            double* dst = partial + snn_bn_partial_index(step, chunk, n0 + tid, chunks, OC);
+            dst[0] = ss;
+            dst[1] = qq;
         }
     }
     __syncthreads();
@@ -738,10 +739,9 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         double* red = reinterpret_cast<double*>(smem);
         static_assert(4 * TN * 32 * 2 * 8 <= SMEM_BYTES, "statistics scratch does not fit");
         const int chunk = (int)(m0 / BM - (bn_t * g.bn_rows) / BM);
-        stat_flush<WM, WN, TN>(s_lo, q_lo, red, g.bn_partial + ((bn_t * g.bn_chunks + chunk) * g.OC) * 2, n0, g.OC, tid);
+        stat_flush<WM, WN, TN>(s_lo, q_lo, red, g.bn_partial, bn_t, chunk, g.bn_chunks, n0, g.OC, tid);
         if (split < m0 + BM && split < g.Mtot)   // this tile is also the first one of the next timestep
-            stat_flush<WM, WN, TN>(s_hi, q_hi, red, g.bn_partial + (((bn_t + 1) * g.bn_chunks) * g.OC) * 2, n0, g.OC,
-                                   tid);
+            stat_flush<WM, WN, TN>(s_hi, q_hi, red, g.bn_partial, bn_t + 1, 0, g.bn_chunks, n0, g.OC, tid);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1430,8 +1430,9 @@ struct DirectGeom {
     int KtotFull;           // 9 * IC
     int out_vec;
     // forward only: statistics partials of the BatchNorm that follows (null: none); a patch lies in ONE frame, so
-    // chunk = the patch's index among the patches of its timestep (frames per step * patches per image of them)
+    // chunk = the patch's index among the patches of its timestep (bn_chunks = frames per step * patches per image)
     double* bn_partial;
+    int bn_chunks;
 };
 constexpr int DPH = 8, DPW = 16, DHW = DPW + 2, DHALO = (DPH + 2) * DHW;  // 180 halo pixels
 constexpr int DHROWS = (DHALO + 7) / 8 * 8;                               // 184 LDS rows (whole groups of 8)
@@ -1747,9 +1748,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
                         qq[j] = fma(d, d, qq[j]);
                     }
             static_assert(4 * TN * 32 * 2 * 8 <= A_BYTES + B_BYTES, "statistics scratch does not fit");
-            // patches are numbered frame by frame, so [t][chunk] flattens to the patch number itself
-            stat_flush<WM, WN, TN>(ss, qq, reinterpret_cast<double*>(smem), g.bn_partial + ((int64_t)e_tile * g.OC) * 2,
-                                   0, g.OC, tid);
+            // patches are numbered frame by frame: timestep = patch number / (patches per timestep)
+            stat_flush<WM, WN, TN>(ss, qq, reinterpret_cast<double*>(smem), g.bn_partial, e_tile / g.bn_chunks,
+                                   e_tile % g.bn_chunks, g.bn_chunks, 0, g.OC, tid);
         }
     #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1796,7 +1797,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_direct3(const float* __res
 template <bool FLIP>
 static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* out, int64_t ldo, int64_t N, int H,
                           int W, int IC, int OC, int split, const float* addend, int64_t ld_add,
-                          const float* addend2, int64_t ld_add2, double* bn_partial, hipStream_t st, const char* name) {
+                          const float* addend2, int64_t ld_add2, double* bn_partial, int bn_chunks, hipStream_t st,
+                          const char* name) {
     static const bool off = snn_tuning_env("SNN_CONV_NO_DIRECT") != nullptr;  // tuning / bisecting aid
     // measured: a win (12-15 %) for <= 32 output channels; at 64 the implicit-GEMM kernel is as fast or faster
     // (both are bound by LDS operand traffic there), so it stays the default; SNN_CONV_DIRECT_MAX_OC=64 to compare
@@ -1818,6 +1820,7 @@ static int launch_direct3(const float* in, int64_t ldi, const float* wk, float* 
     g.out_vec = (ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = bn_partial;
+    g.bn_chunks = bn_chunks;
     // persistent: at most (CUs per XCD) x (resident blocks per CU) blocks per XCD
     const int resident = (OC <= 32 && split != 3) ? 3 : 2;
     int nbx = (snn_num_cu() / 8) * resident;
@@ -1871,7 +1874,7 @@ struct FirstGeom {
     int H, W, Ho, Wo, Cout, stride, pad;
     // Rows are dealt to the blocks in groups: group q = blockIdx / group_blocks owns rows [q, q+1) * group_rows and
     // its group_blocks blocks walk them with that stride.  One group (all rows) unless the forward pass also emits
-    // BatchNorm partials: then a group is a TIMESTEP and block j of it writes chunk j of partial[t][chunk][c][2].
+    // BatchNorm partials: then a group is a TIMESTEP and block j of it writes chunk j of partial[t][c][chunk][2].
     int group_rows, group_blocks;
     double* bn_partial;
 };
@@ -1986,7 +1989,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
                 ss += sred[q * cgs + gq][c];
                 qq += sred[q * cgs + gq][4 + c];
             }
-            double* dst = g.bn_partial + ((int64_t)blockIdx.x * g.Cout + threadIdx.x) * 2;  // [t][chunk] = block id
+            double* dst = g.bn_partial + snn_bn_partial_index(grp, grp_j, threadIdx.x, g.group_blocks, g.Cout);
             dst[0] = ss;
             dst[1] = qq;
         }
@@ -2163,7 +2166,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
         const int64_t chunks = bn_partial ? direct_bn_chunks(frames_per_step, Ho, Wo) : 0;
         const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, fwd_split, addend, ld_addend,
-                                             nullptr, 0, chunks <= 0x7fffffff ? bn_partial : nullptr,
+                                             nullptr, 0, chunks <= 0x7fffffff ? bn_partial : nullptr, (int)chunks,
                                              (hipStream_t)stream, "snn_conv2d_fwd");
         if (rc >= 0) {
             if (rc == 0 && bn_partial && chunks <= 0x7fffffff) bn_layout[0] = (int)chunks;
@@ -2213,7 +2216,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     const bool split = bwd_split != 0;
     if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && bwd_split != SNN_PREC_BF16X1) {  // dx = conv(dy, mirrored taps of w^T)
         const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
-                                            ld_addend, addend2, ld_addend2, nullptr, (hipStream_t)stream,
+                                            ld_addend, addend2, ld_addend2, nullptr, 0, (hipStream_t)stream,
                                             "snn_conv2d_dgrad");
         if (rc >= 0) return rc;
     }

@@ -31,7 +31,7 @@ template <> __device__ __forceinline__ float& lane<1>(float& v, int) { return v;
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics: per (t, c) sum and sum of squares over the M pixels of timestep t.
-// grid = (chunks, T, channel blocks); partial[t][chunk][c][2] in fp64.
+// grid = (chunks, T, channel blocks); partial[t][c][chunk][2] in fp64.
 // ------------------------------------------------------------------------------------------
 struct StatsPlan {
     int vec, cvb, zblocks, chunks;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const float* __restrict__
                 ss += red[((k * cvb + cgl) * VEC + j) * 2 + 0];
                 qq += red[((k * cvb + cgl) * VEC + j) * 2 + 1];
             }
-            double* dst = partial + (((int64_t)t * chunks + chunk) * C + (int64_t)cg * VEC + j) * 2;
+            double* dst = partial + snn_bn_partial_index(t, chunk, (int64_t)cg * VEC + j, chunks, C);
             dst[0] = ss;
             dst[1] = qq;
         }
@@ -119,7 +119,7 @@ __global__ void k_bn_stats_finalize(const double* __restrict__ partial, int chun
     } else {
         double s = 0.0, q = 0.0;
         for (int k = 0; k < chunks; ++k) {
-            const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
+            const double* src = partial + snn_bn_partial_index(t, k, c, chunks, C);
             s += src[0];
             q += src[1];
         }
@@ -178,13 +178,14 @@ __global__ __launch_bounds__(32 * SUB) void k_bn_stats_finalize_fused(
         double s = 0.0, q = 0.0;
         if (!use_running && t < T) {
             const int nk = chunks_of_step(chunks, rows_per_chunk, t, M);
-            const double* base = partial + ((int64_t)t * chunks * C + c) * 2;
+            const double* base = partial;
             int k = sub;
             constexpr int U = SUB >= 32 ? 8 : 4;   // loads in flight (the loop is latency-bound), added in chunk order
             for (; k + (U - 1) * SUB < nk; k += U * SUB) {
                 double2 p[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) p[u] = *reinterpret_cast<const double2*>(base + (int64_t)(k + u * SUB) * C * 2);
+                for (int u = 0; u < U; ++u)
+                    p[u] = *reinterpret_cast<const double2*>(base + snn_bn_partial_index(t, k + u * SUB, c, chunks, C));
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     s += p[u].x;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(32 * SUB) void k_bn_stats_finalize_fused(
                 }
             }
             for (; k < nk; k += SUB) {
-                const double2 p0 = *reinterpret_cast<const double2*>(base + (int64_t)k * C * 2);
+                const double2 p0 = *reinterpret_cast<const double2*>(base + snn_bn_partial_index(t, k, c, chunks, C));
                 s += p0.x; q += p0.y;
             }
         }
@@ -249,7 +250,7 @@ __global__ void k_bn_stats_reduce(const double* __restrict__ partial, int chunks
     double s = 0.0, q = 0.0;
     const int nk = chunks_of_step(chunks, rows_per_chunk, t, M);
     for (int k = 0; k < nk; ++k) {
-        const double* src = partial + (((int64_t)t * chunks + k) * C + c) * 2;
+        const double* src = partial + snn_bn_partial_index(t, k, c, chunks, C);
         s += src[0];
         q += src[1];
     }

@@ -71,4 +71,13 @@ int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx
                           int nprod /* 3: bf16 x 3, 1: bf16 x 1 */, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// BatchNorm statistics partials (fp64 pairs), laid out [t][c][chunk]: the lanes of the finalize kernel that share one
+// (t, c) read consecutive chunks - 512 contiguous bytes per load instruction.  With the chunk index outside the
+// channel ([t][chunk][c], as the producers would like to write it) every lane's 16 bytes sat in a different cache line:
+// 16.2 -> 9.3 us per finalize launch, for 1-4 % more time in the producing epilogues (their stores become 16-byte
+// pieces) - about 0.1 ms per step net.
+__host__ __device__ inline int64_t snn_bn_partial_index(int64_t t, int64_t chunk, int64_t c, int64_t chunks, int64_t C) {
+    return ((t * C + c) * chunks + chunk) * 2;
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
