@@ -40,7 +40,7 @@ PEAK_HBM_GBS = 8000.0
 
 # name -> (H, W, classes, per-GPU batch, T, event density, CPU-baseline sample (B, T))
 CONFIGS = {
-    "gen1": dict(H=GEN1_H, W=GEN1_W, classes=2, batch=5, T=32, p=0.05, cpu_sample=(5, 16),
+    "gen1": dict(H=GEN1_H, W=GEN1_W, classes=2, batch=5, T=32, p=0.05, cpu_sample=(5, 32),
                  label="SODa/TinyYolo (4.23M params) GEN1 304x240"),
     "1mpx": dict(H=720, W=1280, classes=7, batch=8, T=32, p=0.05, cpu_sample=(1, 4),
                  label="SODa/TinyYolo (4.26M params) 1Mpx 1280x720, 7 classes"),
@@ -99,14 +99,10 @@ def deep12_probe(B, H, W, device):
 
 
 def csrc_fingerprint() -> str:
-    """sha256 over the kernel sources: ties a PMC traffic file to the kernels it was measured on."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "snn_for_object_detection_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
-    return h.hexdigest()
+    """sha256 over the kernel sources: ties a PMC traffic file to the kernels it was measured on (the digest the build
+    stamps ``libsnn_hip.so`` with, ``_build.source_fingerprint``)."""
+    from snn_for_object_detection_amd._build import source_fingerprint
+    return source_fingerprint()
 
 
 def pmc_traffic(config: str, kernel: str):
@@ -172,6 +168,41 @@ def cpu_baseline(config, H, W, num_classes, threads, p):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """Run this script as ``n`` ranks of one node under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1) and return the launcher's exit code; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """The multi-process control flow without a GPU: rendezvous, one all-reduce, the rank-0 JSON line."""
+    import torch.distributed as dist
+    backend = None
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("SNN_DIST_BACKEND", "gloo"))
+        backend = dist.get_backend()
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd", "value": None,
+                          "unit": "event-frames/s", "n_gpus": world, "dry_run": True,
+                          "dist": {"backend": backend, "world_size": world, "ranks_in_allreduce": seen}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +226,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch / rendezvous / collective control flow only: no GPU work, no timing; "
+                         "the JSON line carries n_gpus and dist but value null (CPU boxes, SNN_DIST_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves - BEFORE anything touches the GPU
+        # (no HIP call has happened in this process; the ranks are child processes, this one only relays their exit code)
+        raise SystemExit(spawn_ranks(args.gpus))
     cfg = CONFIGS[args.config]
     T = args.timesteps or cfg["T"]
     B = args.batch or cfg["batch"]
@@ -209,8 +249,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never measure a different number of GPUs than the one asked for (the line would carry the wrong n_gpus)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if world > torch.cuda.device_count() and os.environ.get("SNN_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs (RCCL needs one GPU per "
+                         "rank; SNN_DIST_BACKEND=gloo rehearses the control flow on fewer)")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -225,8 +273,6 @@ def main():
         else:
             dist.init_process_group(backend)
         backend = dist.get_backend()
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     import snn_for_object_detection_amd as S
     from snn_for_object_detection_amd import _hip
@@ -398,7 +444,11 @@ def main():
                 "peak_hbm_gib": peak_gib,
             },
             "dist": {"backend": backend, "world_size": world,
-                     "gradient_exchange": "one SUM all-reduce of the flat fp32 gradient per step" if world > 1 else None,
+                     "gradient_exchange": ("SUM all-reduce of the flat fp32 gradient: neck + head part started from a backward "
+                                           "hook at the backbone / neck boundary (overlaps the backbone's backward "
+                                           "pass), backbone part in step()" if getattr(trainer, "_early_lo", None)
+                                           else "one SUM all-reduce of the flat fp32 gradient per step")
+                     if world > 1 else None,
                      "replicas_equal_after_run": replicas_equal},
             "roofline": roofline,
             "cpu_baseline": cpu,

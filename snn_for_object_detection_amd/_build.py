@@ -2,9 +2,18 @@
 
 ``python -m snn_for_object_detection_amd._build`` or ``__graft_entry__.build()``.
 The library links only against the HIP runtime - no torch types cross the ABI
-(``include/snn_hip.h``).  Objects are rebuilt when a source or header is newer.
+(``include/snn_hip.h``).
+
+What is rebuilt is decided by CONTENT, not by file times: every object carries a stamp
+(``csrc/<name>.o.buildstamp``) holding the sha256 of its source, the shared headers, the compiler
+flags and ``hipcc --version``; the library's stamp (``libsnn_hip.so.buildstamp``) holds the
+fingerprint of all kernel sources (``source_fingerprint()``, the same digest ``bench.py`` ties its PMC
+traffic files to).  A shipped binary next to edited sources is therefore detected - by ``build()``,
+which recompiles, and by ``_hip.load()``, which refuses to run a stale library.
 """
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -14,9 +23,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+SCRATCH = os.path.join(os.path.dirname(HERE), "build")   # tuning / stamp / clock libraries: never in the package
 LIB_NAME = "libsnn_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
+STAMP_PATH = LIB_PATH + ".buildstamp"
 SOURCES = ("elementwise.hip", "neuron.hip", "conv.hip", "wgrad_halo.hip", "detect.hip", "targets.hip")
+HEADERS = (os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h"))
 ARCH = "gfx950"
 # -ffp-contract=off: the pointwise kernels must round like the reference's unfused torch ops.
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall",
@@ -30,32 +42,65 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
-def _newer(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(*chunks: bytes) -> str:
+    h = hashlib.sha256()
+    for c in chunks:
+        h.update(c)
+    return h.hexdigest()
+
+
+def source_fingerprint() -> str:
+    """sha256 over every ``csrc/*.hip`` / ``*.h`` (name + bytes, sorted) and ``include/snn_hip.h``."""
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(open(os.path.join(INCLUDE, "snn_hip.h"), "rb").read())
+    return h.hexdigest()
+
+
+def _read_stamp(path: str) -> dict:
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def library_is_current() -> bool:
+    """True when ``libsnn_hip.so`` exists and was built from the kernel sources as they are now."""
+    return os.path.exists(LIB_PATH) and _read_stamp(STAMP_PATH).get("sources") == source_fingerprint()
+
+
+def _compiler_id(hipcc: str) -> str:
+    res = subprocess.run([hipcc, "--version"], capture_output=True, text=True)
+    return _sha(res.stdout.encode())[:16]
 
 
 def build(force: bool = False, verbose: bool = False, tuning: bool = False, stamp: bool = False,
           clock: bool = False) -> str:
     """``tuning=True`` (``--tuning``): compile the bisecting / tuning environment knobs in (``-DSNN_TUNING``) and write
-    ``libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment.
+    ``build/libsnn_hip_tuning.so`` (load it with ``SNN_HIP_LIB=...``); the product library reads no environment.
     ``stamp=True`` (``--stamp``): additionally ``-DSNN_STAMP`` (in-kernel cycle stamps of the conv main loop,
-    ``tools/stamp_conv.py``) -> ``libsnn_hip_stamp.so``.
+    ``tools/stamp_conv.py``) -> ``build/libsnn_hip_stamp.so``.
     ``clock=True`` (``--clock``): ``-DSNN_CLOCK`` only (begin / end stamps of the shader and the wall clock per block: the
-    clock the chip holds under the kernel's load, ``tools/clock_conv.py``) -> ``libsnn_hip_clock.so``."""
+    clock the chip holds under the kernel's load, ``tools/clock_conv.py``) -> ``build/libsnn_hip_clock.so``."""
+    if not (force or tuning or stamp or clock) and library_is_current():
+        return LIB_PATH   # the shipped binary matches the sources: nothing to do (and no hipcc needed)
     hipcc = _hipcc()
     if tuning or stamp or clock:
         return _build_tuning(hipcc, verbose, stamp, clock)
-    headers = [os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h")]
+    cc = _compiler_id(hipcc)
+    header_bytes = b"".join(open(h, "rb").read() for h in HEADERS)
     objs, jobs = [], []
     for src in SOURCES:
         spath = os.path.join(CSRC, src)
         opath = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(opath)
-        if force or _newer(opath, [spath] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", spath, "-o", opath])
+        key = _sha(open(spath, "rb").read(), header_bytes, " ".join(FLAGS).encode(), cc.encode())
+        if force or not os.path.exists(opath) or _read_stamp(opath + ".buildstamp").get("key") != key:
+            jobs.append(([hipcc, *FLAGS, "-c", spath, "-o", opath], opath, key))
 
     def run(cmd):
         if verbose:
@@ -66,16 +111,27 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, stam
         if verbose and res.stderr.strip():
             print(res.stderr, file=sys.stderr)
 
+    def compile_one(job):
+        cmd, opath, key = job
+        run(cmd)
+        with open(opath + ".buildstamp", "w") as f:
+            json.dump({"key": key}, f)
+
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
-            list(pool.map(run, jobs))
-    if force or jobs or _newer(LIB_PATH, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
+            list(pool.map(compile_one, jobs))
+    if os.path.exists(STAMP_PATH):
+        os.remove(STAMP_PATH)   # never leave a stamp that vouches for a half-written library
+    run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
+    with open(STAMP_PATH, "w") as f:
+        json.dump({"sources": source_fingerprint(), "flags": FLAGS, "hipcc": cc}, f)
     return LIB_PATH
 
 
 def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False, clock: bool = False) -> str:
-    out = os.path.join(HERE, "libsnn_hip_stamp.so" if stamp else "libsnn_hip_clock.so" if clock else "libsnn_hip_tuning.so")
+    os.makedirs(SCRATCH, exist_ok=True)
+    out = os.path.join(SCRATCH, "libsnn_hip_stamp.so" if stamp else "libsnn_hip_clock.so" if clock
+                       else "libsnn_hip_tuning.so")
     cmd = [hipcc, *FLAGS, "-DSNN_TUNING", *(["-DSNN_STAMP"] if stamp else []), *(["-DSNN_CLOCK"] if clock else []),
            "-shared",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]

@@ -99,6 +99,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the gfx950 HIP extension has not been built "
             "(run `python -m snn_for_object_detection_amd._build`); there is no CPU / eager fallback")
+    if not os.environ.get("SNN_HIP_LIB"):
+        # a binary shipped next to edited sources must not run silently (it is keyed on the sources' sha256, _build.py)
+        from . import _build
+        if not _build.library_is_current():
+            raise RuntimeError(
+                f"{LIB_PATH} was not built from the kernel sources as they are now (csrc/*.hip, include/snn_hip.h "
+                "changed, or the build stamp is missing): run `python -m snn_for_object_detection_amd._build`")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lacks a declared symbol

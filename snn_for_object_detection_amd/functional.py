@@ -486,8 +486,8 @@ class _Conv2d(Function):
         # FlatTrainer keeps a pre-split image of the weights (valid while the version counter matches): ready-made pieces
         w16 = None
         if (fwd_prec == _hip.PREC_FP16X3 and USE_PRESPLIT_WEIGHTS and w_ohwi is w
-                and getattr(weight, "_snn_w16_ptr", None) is not None and weight._snn_wt_version == weight._version):
-            w16 = weight._snn_w16_ptr
+                and getattr(weight, "_snn_w16", None) is not None and weight._snn_wt_version == weight._version):
+            w16 = weight._snn_w16.data_ptr()   # a tensor view on the parameter: alive as long as the parameter is
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), w16, y.data_ptr(), cl_stride(y),
                   T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec,
                   _stream())
@@ -515,7 +515,7 @@ class _Conv2d(Function):
             if wref is not None and wref._snn_wt_version == wref._version:
                 wt = wref._snn_wt  # transposed once per optimiser step for all layers (trainer.FlatTrainer)
                 if ctx.prec == _hip.PREC_BF16X3 and USE_PRESPLIT_WEIGHTS and USE_PRESPLIT_DGRAD:
-                    wt16 = getattr(wref, "_snn_wt16_ptr", None)   # ... and pre-split into its bf16 pieces
+                    wt16 = _ptr(getattr(wref, "_snn_wt16", None))   # ... and pre-split into its bf16 pieces
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
@@ -790,7 +790,8 @@ class _AffineNeuron(Function):
         vdec = None
         ckpt = False
         if neuron in _SAVES_STEP and need_grad:
-            ckpt = (neuron == _hip.NEURON_LIF and LIF_CHECKPOINT_BYTES is not None
+            # (the checkpointed kernels write / read all T outputs: not for the last-step-only read-out)
+            ckpt = (neuron == _hip.NEURON_LIF and LIF_CHECKPOINT_BYTES is not None and not last_only
                     and T * M * C * 4 >= LIF_CHECKPOINT_BYTES)
             if ckpt:
                 k = _hip.query("snn_lif_ckpt_interval")
@@ -1233,6 +1234,33 @@ def sum_tensors(xs: List[torch.Tensor], dest: Optional[Dest] = None) -> torch.Te
     seqs = [as_sequence(x) for x in xs]
     out = _Sum.apply(dest, *[s for s, _ in seqs])
     return out[0] if seqs[0][1] else out
+
+
+class _GradReady(Function):
+    """Identity whose backward first calls ``fn()``: marks the point of the backward pass at which every gradient
+    produced downstream of ``x`` (in forward order) is complete or enqueued - ``FlatTrainer.early_all_reduce``."""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        acc = _acc_of(x)
+        out = torch.empty(0, device=x.device, dtype=x.dtype)
+        out.set_(x.untyped_storage(), x.storage_offset(), x.size(), x.stride())
+        if acc is not None:
+            out._snn_acc = acc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def grad_ready_hook(x: torch.Tensor, fn) -> torch.Tensor:
+    """``x`` unchanged; during the backward pass ``fn()`` runs when the gradient of ``x`` arrives."""
+    if fn is None or not x.requires_grad:
+        return x
+    return _GradReady.apply(x, fn)
 
 
 # ------------------------------------------------------------------------------------------- pointwise / pooling

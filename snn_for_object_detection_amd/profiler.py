@@ -55,13 +55,18 @@ def work_of(name: str, a):
         return _conv_label(name, a), flops, byts
     if name == "snn_affine_neuron_fwd":
         neuron, T, M, C = a[0], a[14], a[15], a[16]
-        tensors = 2 + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)  # + vdec, + fused shortcut
+        last_only = bool(a[18] & 2)   # SNN_SCAN_LAST_STEP_ONLY: the output of ONE step is written
         elems = float(T) * M * C
+        # y read; out written (one step of it with last_only); + vdec, + fused shortcut
+        tensors = 1 + (1.0 / T if last_only else 1) + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)
         return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * tensors
     if name == "snn_affine_neuron_bwd":
         neuron, T, M, C = a[0], a[15], a[16], a[17]
+        last_only = bool(a[19] & 2)   # output gradient (and a saved OUTPUT, LI+Tanh) exist for the last step only
         elems = float(T) * M * C
-        tensors = 2 + (1 if a[3] is not None else 0) + (1 if a[14] is not None else 0)
+        one = 1.0 / T if last_only else 1
+        saved = 0 if a[3] is None else (one if neuron == 3 else 1)   # LIF & co. save v_dec per step, LI+Tanh its output
+        tensors = one + 1 + saved + (1 if a[14] is not None else 0)   # g_out, gx, saved state, y (for the BN sums)
         return f"k_affine_neuron_bwd<{neuron}>", 16.0 * elems, 4.0 * elems * tensors
     if name == "snn_lif_fwd_ckpt":  # y, out (+ shortcut), checkpoints = 2/K of a tensor
         T, M, C = a[13], a[14], a[15]

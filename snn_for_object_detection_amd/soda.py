@@ -45,6 +45,10 @@ class SODa(nn.Module):
         )
         self.plotter = plotter
         self.logged = {}
+        self._sync_logged = set()
+        # set by trainer.FlatTrainer.attach(): called in the backward pass when it crosses the backbone / neck boundary
+        # (every neck and head gradient is complete or enqueued there) to start their all-reduce early
+        self._snn_neck_grads_ready = None
 
         self.base_net = BackboneGen(self.backbone_cfgs, in_channels=2, init_weights=self.hparams.init_weights)
         self.neck_net = NeckGen(self.neck_cfgs, self.base_net.out_channels, init_weights=self.hparams.init_weights)
@@ -68,8 +72,26 @@ class SODa(nn.Module):
     def configure_optimizers(self) -> torch.optim.Optimizer:
         return torch.optim.Adamax(self.parameters(), lr=self.hparams.learning_rate)
 
-    def log(self, name, value, **kwargs) -> None:
+    def log(self, name, value, sync_dist: bool = False, **kwargs) -> None:
+        """Lightning's ``self.log`` reduced to a dict.  ``sync_dist=True`` (every loss the reference logs,
+        ``soda.py:151-157``) marks the entry for the cross-rank mean, which ``synced_logs()`` takes with ONE all-reduce
+        over all marked entries when the values are actually read - not one collective per logged value per step."""
         self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+        if sync_dist:
+            self._sync_logged.add(name)
+
+    def synced_logs(self, process_group=None) -> dict:
+        """The logged values with the ``sync_dist`` entries averaged over the ranks (Lightning's reduction)."""
+        import torch.distributed as dist
+        out = dict(self.logged)
+        names = sorted(n for n in self._sync_logged if isinstance(out.get(n), torch.Tensor))
+        if names and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            flat = torch.stack([out[n].float().reshape(()) for n in names])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+            flat = flat / dist.get_world_size(process_group)
+            for k, n in enumerate(names):
+                out[n] = flat[k]
+        return out
 
     # ------------------------------------------------------------------ forward
     def forward(self, X: torch.Tensor, time_outer: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -88,6 +110,8 @@ class SODa(nn.Module):
         HF.begin_counter_batch()
         try:
             base_out, state[0] = self.base_net.forward(X, state[0])
+            if self._snn_neck_grads_ready is not None and base_out.dim() == 5:
+                base_out = HF.grad_ready_hook(base_out, self._snn_neck_grads_ready)
             neck_out, state[1] = self.neck_net.forward(base_out, state[1])
             anchors, cls_preds, bbox_preds, state[2] = self.head_net.forward(neck_out, state[2])
         finally:
@@ -128,10 +152,11 @@ class SODa(nn.Module):
         return prep_pred, state
 
     def _rand_start_time(self) -> int:
-        # soda.py:246-257: drop a random prefix of the sequence
+        # soda.py:246-257: drop a random prefix of the sequence; the SAME draw (``requires_grad=False``,
+        # ``dtype=torch.uint32``: a seeded run consumes the generator exactly as the reference does)
         if not self.hparams.time_window:
             return 0
-        return int(torch.randint(0, self.hparams.time_window, (1,)).item())
+        return int(torch.randint(0, self.hparams.time_window, (1,), requires_grad=False, dtype=torch.uint32).item())
 
     def _loss(self, preds: Tuple[torch.Tensor, torch.Tensor, torch.Tensor], labels: torch.Tensor) -> torch.Tensor:
         # soda.py:259-281

@@ -43,7 +43,8 @@ class FlatTrainer:
     """
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = False):
+                 process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = False,
+                 overlap_grad_exchange: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise RuntimeError("model has no trainable parameters")
@@ -56,7 +57,9 @@ class FlatTrainer:
         self.exp_inf = torch.zeros(total_padded, device=dev, dtype=torch.float32)
         self.numel = total
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.step_count = 0
+        self.step_count = 0                       # optimiser steps taken by this trainer
+        # torch.optim.Adamax keeps ``step`` PER PARAMETER and does not advance it for a parameter without a gradient
+        self.param_steps: List[int] = [0] * len(self.params)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.slots: List[GradSlot] = []
@@ -76,6 +79,11 @@ class FlatTrainer:
         for p in self.params:
             if p.dtype != torch.float32:
                 raise RuntimeError("FlatTrainer: float32 parameters only")
+            # an earlier trainer's cached images must not outlive it on the parameter (they would pass the version check)
+            for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_grad_slot"):
+                if hasattr(p, name):
+                    delattr(p, name)
+            p._snn_wt_version = -1
             view = _storage_view(self.flat_param, off, p.data)
             view.copy_(p.data)
             p.data = view
@@ -91,10 +99,11 @@ class FlatTrainer:
                 p._snn_wt = self.flat_wt[off:off + p.numel()].view(i, kh, kw, o)
                 p._snn_wt_version = -1  # not valid yet
                 # rows of both matrices must start on a 4-float group of the flat buffers
+                # (tensor VIEWS, not addresses: the parameter keeps the image alive after the trainer is gone)
                 if off % 4 == 0 and (kh * kw * i) % 4 == 0 and (kh * kw * o) % 4 == 0:
-                    p._snn_w16_ptr = self.flat_w16.data_ptr() + 4 * off
+                    p._snn_w16 = self.flat_w16[off:off + p.numel()]
                     if self.flat_wt16 is not None:
-                        p._snn_wt16_ptr = self.flat_wt16.data_ptr() + 4 * off
+                        p._snn_wt16 = self.flat_wt16[off:off + p.numel()]
                 self._conv_params.append(p)
             off += p.numel()
         self._wt_table = torch.tensor(table, dtype=torch.int64, device=dev) if table else None
@@ -110,7 +119,50 @@ class FlatTrainer:
         self._float_buffers = [b for b in model.buffers() if b.is_floating_point()]
         self._int_buffers = [b for b in model.buffers() if not b.is_floating_point() and b.numel() == 1]
         self.broadcast_buffers = broadcast_buffers
+        # gradient exchange overlapped with the backward pass: see ``overlap_from``
+        self._early_lo: Optional[int] = None
+        self._early_work = None
+        self._comm_stream = None
+        self._flags_work = None
+        self._flags = None
+        if (overlap_grad_exchange and self.world > 1 and hasattr(model, "_snn_neck_grads_ready")
+                and all(hasattr(model, a) for a in ("neck_net", "head_net"))):
+            # a SODa detector: neck + head gradients go out while the backbone's backward pass still runs
+            self.overlap_from([model.neck_net, model.head_net])
+            model._snn_neck_grads_ready = self.early_all_reduce
         self.refresh_transposed_weights()
+
+    # ------------------------------------------------------------------ overlapped gradient exchange
+    def overlap_from(self, modules: Iterable[torch.nn.Module]) -> int:
+        """Arrange for the gradients of every parameter of ``modules`` to be all-reduced as soon as the backward pass
+        has produced them (``early_all_reduce()``, called from a backward hook), while the rest of the backward pass
+        still runs; ``step()`` then exchanges only what is left.  The parameters must form the TAIL of the flat buffer
+        (for ``SODa``: neck + head = 93 % of TinyYolo, whose gradients are complete when the backward pass crosses the
+        backbone / neck boundary).  Returns the first flat index of the early part."""
+        ids = {id(p) for m in modules for p in m.parameters() if p.requires_grad}
+        first = next((k for k, p in enumerate(self.params) if id(p) in ids), None)
+        if first is None or any(id(p) not in ids for p in self.params[first:]) or len(ids) != len(self.params) - first:
+            raise RuntimeError("overlap_from: the modules' parameters are not the tail of the trainer's parameter order")
+        self._early_lo = self._offsets[first]
+        return self._early_lo
+
+    def early_all_reduce(self) -> None:
+        """Start the all-reduce of ``flat_grad[early_lo:]`` on a communication stream behind everything the main and
+        the weight-gradient streams hold at this point.  No-op for a single rank or without ``overlap_from``."""
+        if self.world <= 1 or self._early_lo is None or self._early_work is not None:
+            return
+        part = self.flat_grad[self._early_lo:]
+        if part.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=part.device)
+            comm = self._comm_stream
+            comm.wait_stream(torch.cuda.current_stream())
+            for st in _HF._SIDE_STREAMS.values():
+                comm.wait_stream(st)
+            with torch.cuda.stream(comm):
+                self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def refresh_transposed_weights(self) -> None:
         """Re-derive every ``p._snn_wt`` from the current weights (one launch).  ``_Conv2d.backward`` uses a cached
@@ -132,6 +184,9 @@ class FlatTrainer:
     def zero_grad(self) -> None:
         if self.flat_grad.is_cuda:
             wgrad_stream_sync()  # nothing may still be writing into the buffer that is about to be cleared
+        if self._early_work is not None:   # a backward pass whose step() never came: let its collective finish first
+            self._early_work.wait()
+            self._early_work = None
         self.flat_grad.zero_()
         for p, slot in zip(self.params, self.slots):
             slot.written = False
@@ -149,31 +204,54 @@ class FlatTrainer:
                 p.grad = None
 
     def all_reduce(self) -> None:
-        """One SUM all-reduce of the whole flat gradient (averaging is folded into the Adamax kernel)."""
-        if self.world > 1:
+        """SUM all-reduce of the flat gradient (averaging is folded into the Adamax kernel): ONE collective over the whole
+        buffer, or - when ``early_all_reduce()`` already sent the tail during the backward pass - one over the head
+        that was still being written then, joined with the early one."""
+        if self.world <= 1:
+            return
+        if self._early_work is not None:
+            if self._early_lo > 0:
+                dist.all_reduce(self.flat_grad[: self._early_lo], op=dist.ReduceOp.SUM, group=self.group)
+            self._early_work.wait()            # the current stream waits for the collective
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._early_work = None
+        else:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _written_ranges(self) -> List[Tuple[int, int]]:
-        """Element ranges of the flat buffers that received a gradient this step, adjacent parameters coalesced.
-        ``torch.optim.Adamax`` skips parameters whose ``.grad`` is None (their moments do not decay and the parameter
-        does not move); the fused kernel is launched per written range to keep that behaviour.  With data parallelism
-        a parameter counts as written when ANY rank wrote it (the all-reduce delivers the others' gradients)."""
+    def _written_flags(self) -> List[bool]:
+        """Which parameters received a gradient this step.  ``torch.optim.Adamax`` skips parameters whose ``.grad`` is
+        None (their moments do not decay, the parameter does not move, its ``step`` does not advance).  With data
+        parallelism a parameter counts as written when ANY rank wrote it (the all-reduce delivers the others'
+        gradients).  EVERY rank enters the flag exchange in EVERY step (a rank-local condition in front of a collective
+        hangs the ranks that took the other branch); only a rank that itself skipped a parameter reads the result."""
         written = [slot.written for slot in self.slots]
-        if self.world > 1 and not all(written):
+        if self.world > 1:
             flags = torch.tensor(written, dtype=torch.int32, device=self.flat_grad.device)
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-            written = [bool(f) for f in flags.tolist()]
-        if all(written):
-            return [(0, self.flat_param.numel())]   # the common case: one launch over the padded buffer
-        ranges: List[Tuple[int, int]] = []
+            work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+            if all(written):
+                # whatever the other ranks did, the union is "all written": no host round trip.  The handle is kept
+                # until the next step so the tensor outlives the collective.
+                self._flags, self._flags_work = flags, work
+            else:
+                work.wait()
+                written = [bool(f) for f in flags.tolist()]
+        return written
+
+    def _ranges(self, written: List[bool]) -> List[Tuple[int, int, int]]:
+        """``(lo, hi, step)`` element ranges for the fused Adamax kernel: adjacent written parameters with the same
+        (already advanced) step count coalesced; the common case is one launch over the padded buffer."""
+        ranges: List[Tuple[int, int, int]] = []
         for k, w in enumerate(written):
             if not w:
                 continue
-            lo, hi = self._offsets[k], self._offsets[k + 1]
-            if ranges and ranges[-1][1] == lo:
-                ranges[-1] = (ranges[-1][0], hi)
+            lo, hi, stp = self._offsets[k], self._offsets[k + 1], self.param_steps[k]
+            if ranges and ranges[-1][1] == lo and ranges[-1][2] == stp:
+                ranges[-1] = (ranges[-1][0], hi, stp)
             else:
-                ranges.append((lo, hi))
+                ranges.append((lo, hi, stp))
+        if len(ranges) == 1 and ranges[0][:2] == (0, self.numel):
+            ranges[0] = (0, self.flat_param.numel(), ranges[0][2])   # include the padding: whole 16-byte groups
         return ranges
 
     def _check_bindings(self) -> None:
@@ -206,14 +284,20 @@ class FlatTrainer:
         wgrad_stream_sync()  # weight-gradient kernels run on a side stream (functional._Conv2d.backward)
         self._check_bindings()
         self._collect_autograd_grads()
-        ranges = self._written_ranges()
+        if self._flags_work is not None:     # last step's flag exchange (never read): let it retire before the next one
+            self._flags_work.wait()
+            self._flags_work = self._flags = None
+        written = self._written_flags()
         self.all_reduce()
         self.step_count += 1
+        for k, w in enumerate(written):
+            if w:
+                self.param_steps[k] += 1
         st = torch.cuda.current_stream().cuda_stream
-        for lo, hi in ranges:
+        for lo, hi, stp in self._ranges(written):
             _hip.call("snn_adamax_step", self.flat_param.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + 4 * lo,
                       self.exp_avg.data_ptr() + 4 * lo, self.exp_inf.data_ptr() + 4 * lo, hi - lo, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / self.world, st)
+                      self.betas[0], self.betas[1], self.eps, stp, 1.0 / self.world, st)
         self.refresh_transposed_weights()
         if self.broadcast_buffers:
             self.sync_buffers()
@@ -228,12 +312,15 @@ class FlatTrainer:
 
     def state_dict(self) -> Dict:
         """Optimiser state in ``torch.optim.Adamax.state_dict()`` form: ``state[k] = {step, exp_avg, exp_inf}`` for the
-        k-th trainable parameter (tensors in the parameter's LOGICAL shape), one param group.  Interchangeable with a
+        k-th trainable parameter that has received a gradient (tensors in the parameter's LOGICAL shape; ``step`` is kept
+        per parameter, as torch does), one param group.  Interchangeable with a
         ``torch.optim.Adamax`` built over the same parameter order (the reference's Lightning checkpoints carry that
         state, ``models/soda.py:135-136``).  Weights and BatchNorm buffers are the model's own ``state_dict()``."""
         state = {}
         for k, p in enumerate(self.params):
-            state[k] = {"step": torch.tensor(float(self.step_count)),
+            if self.param_steps[k] == 0:   # torch creates a parameter's state at its first gradient
+                continue
+            state[k] = {"step": torch.tensor(float(self.param_steps[k])),
                         "exp_avg": _storage_view(self.exp_avg, self._offsets[k], p.data).clone(),
                         "exp_inf": _storage_view(self.exp_inf, self._offsets[k], p.data).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "foreach": None,
@@ -249,7 +336,7 @@ class FlatTrainer:
         if group.get("weight_decay", 0) or group.get("maximize", False):
             raise RuntimeError("FlatTrainer: weight_decay / maximize are not supported by the fused Adamax kernel")
         self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
-        steps = set()
+        self.param_steps = [0] * len(self.params)
         self.exp_avg.zero_()
         self.exp_inf.zero_()
         for k, p in enumerate(self.params):
@@ -262,10 +349,8 @@ class FlatTrainer:
                     raise RuntimeError(f"optimizer state {name}[{k}] has shape {tuple(t.shape)}, parameter "
                                        f"{tuple(p.shape)}")
                 _storage_view(flat, self._offsets[k], p.data).copy_(t)
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise RuntimeError("FlatTrainer: per-parameter step counts differ; the fused kernel keeps one count")
-        self.step_count = steps.pop() if steps else 0
+            self.param_steps[k] = int(float(st["step"]))
+        self.step_count = max(self.param_steps) if self.param_steps else 0
 
     # ------------------------------------------------------------------ helpers for tests / checkpoints
     def synchronize(self) -> None:

@@ -6,7 +6,8 @@ Loads ``utils/box.py``, ``utils/anchors.py``, ``utils/roi.py`` and ``models/modu
 reference BY FILE PATH (the package ``__init__`` files pull in Lightning / OpenCV / norse, which are not
 installed), runs them on seeded inputs and stores inputs + outputs in ``tests/golden/*.npz``.  The network
 DESCRIPTION ``models/tiny_yolo.py`` is executed against recording stand-ins of the layer generators (it only
-builds nested lists) and its structure stored as ``tiny_yolo_desc.json``.  Only data is stored - no reference
+builds nested lists) and its structure stored as ``tiny_yolo_desc.json``.  The step functions of ``models/modules/sli.py``
+and ``models/modules/synapse.py`` run unmodified (``sli.npz`` / ``synapse.npz``).  Only data is stored - no reference
 source.  The fixtures pin ``oracle/detect.py`` and the product's ``anchors/box/roi`` modules
 (``tests/test_oracle_detect.py``).  ``/root/reference`` never travels to the GPU box; the fixtures do.
 """
@@ -86,6 +87,70 @@ def convlstm_golden(gen):
     np.savez_compressed(os.path.join(OUT, "convlstm.npz"), weight=w.numpy(), x=x.detach().numpy(), gh=gh.numpy(),
                         gc=gc.numpy(), h=torch.stack(hs).detach().numpy(), c=torch.stack(cs).detach().numpy(),
                         gx=x.grad.numpy(), gw=cell.conv.weight.grad.numpy())
+
+
+def sli_synapse_golden(gen):
+    """``models/modules/sli.py:110-126`` (``sli_feed_forward_step``) and ``models/modules/synapse.py:73-103``
+    (``synapse_feed_forward_step``): the reference's own step FUNCTIONS, executed over seeded sequences with autograd.
+    Both files import norse only for the base classes of their Cell wrappers (``SNNCell`` / ``SNN``); empty stand-in
+    classes satisfy that import, the step functions themselves are plain torch and run unmodified.  The SLI step is
+    the only in-tree witness of norse's LI ordering (current jump first, then the voltage update from the jumped
+    current), so it is pinned as DATA here: ``sli.npz`` / ``synapse.npz`` hold inputs, per-step outputs, final state and
+    the gradients of a seeded scalar loss."""
+    snn = types.ModuleType("norse.torch.module.snn")
+    snn.SNNCell = type("SNNCell", (), {"__init__": lambda self, *a, **k: None})
+    snn.SNN = type("SNN", (), {"__init__": lambda self, *a, **k: None})
+    names = ("norse", "norse.torch", "norse.torch.module", "norse.torch.module.snn")
+    saved = {k: sys.modules.get(k) for k in names}
+    for k in names[:-1]:
+        m = types.ModuleType(k)
+        m.__path__ = []
+        sys.modules[k] = m
+    sys.modules[names[-1]] = snn
+    try:
+        sli = _load("ref_sli", os.path.join(REF, "models", "modules", "sli.py"))
+        syn = _load("ref_synapse", os.path.join(REF, "models", "modules", "synapse.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    T, B, C, H, W = 6, 2, 3, 4, 5
+    # ---- SLI: inputs large enough for |v| to approach the saturation potential (sigmoid(v_st - |v|) far from 1/2)
+    x = (8.0 * torch.randn(T, B, C, H, W, generator=gen)).requires_grad_()
+    gv = torch.randn(T, B, C, H, W, generator=gen)
+    gi = torch.randn(B, C, H, W, generator=gen)
+    p = sli.SLIParameters()
+    v0 = p.v_leak.detach().clone().requires_grad_()          # SLICell.initial_state (sli.py:97-107)
+    state = sli.SLIState(v=v0, i=torch.zeros(B, C, H, W))
+    vs = []
+    for t in range(T):
+        v, state = sli.sli_feed_forward_step(x[t], state, p, 0.001)
+        vs.append(v)
+    vs = torch.stack(vs)
+    ((vs * gv).sum() + (state.i * gi).sum()).backward()
+    np.savez_compressed(os.path.join(OUT, "sli.npz"), x=x.detach().numpy(), gv=gv.numpy(), gi=gi.numpy(),
+                        v=vs.detach().numpy(), i_final=state.i.detach().numpy(), gx=x.grad.numpy(),
+                        gv0=v0.grad.numpy(), dt=0.001)
+    # ---- Synapse: signed inputs (secretion for x > 0, dissociation otherwise), without and with inhibition
+    out = {}
+    xs = torch.randn(T, B, C, H, W, generator=gen)
+    gg = torch.randn(T, B, C, H, W, generator=gen)
+    out.update(x=xs.numpy(), gg=gg.numpy(), dt=0.001)
+    for tag, sigma in (("s0", 0.0), ("s07", 0.7)):
+        pp = syn.SynapseParameters(sigma_inhibition=torch.as_tensor(sigma))
+        xin = xs.clone().requires_grad_()
+        st = syn.SynapseState(p=torch.zeros(B, C, H, W))
+        gs = []
+        for t in range(T):
+            g, st = syn.synapse_feed_forward_step(xin[t], st, pp, 0.001)
+            gs.append(g)
+        gs = torch.stack(gs)
+        (gs * gg).sum().backward()
+        out.update({f"g_{tag}": gs.detach().numpy(), f"p_final_{tag}": st.p.detach().numpy(),
+                    f"gx_{tag}": xin.grad.numpy(), f"sigma_{tag}": sigma})
+    np.savez_compressed(os.path.join(OUT, "synapse.npz"), **out)
 
 
 def tiny_yolo_description():
@@ -219,6 +284,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "detect_nms_mid.npz"), anchors=anc_m.numpy(), probs=probs.numpy(),
                         offsets=offp.numpy(), detections=det.numpy())
     convlstm_golden(gen)
+    sli_synapse_golden(gen)
     tiny_yolo_description()
     print("golden vectors written to", OUT)
 

@@ -48,3 +48,105 @@ def test_flat_gradient_allreduce_world2(tmp_path):
     want = (r0["local"] + r1["local"]) / world
     assert torch.allclose(r0["avg"], want, rtol=0, atol=1e-7) and torch.equal(r0["avg"], r1["avg"])
     assert r0["n"] == 2 * 8 * 9 + 8 + 8 * 4
+
+
+def _flags_worker(rank, world, port, out_dir):
+    """One rank leaves a parameter unwritten: EVERY rank must still enter the flag exchange (a rank-local condition in
+    front of the collective would leave the other rank waiting forever) and both see the union."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import FlatTrainer
+        torch.manual_seed(1)
+        blk = S.BlockGen(2, [S.Conv(8, 3, 2), S.Norm(), S.LIF(), S.Conv(4, 1)])
+        tr = FlatTrainer(blk, lr=1e-3)
+        results = []
+        for step in range(3):
+            tr.zero_grad()
+            for k, slot in enumerate(tr.slots):
+                # step 0: rank 1 skips parameter 1;  step 1: both skip parameter 2;  step 2: everything written
+                slot.written = not ((step == 0 and rank == 1 and k == 1) or (step == 1 and k == 2))
+            if tr._flags_work is not None:
+                tr._flags_work.wait()
+                tr._flags_work = tr._flags = None
+            results.append(tr._written_flags())
+        torch.save(results, os.path.join(out_dir, f"flags{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_written_flag_exchange_is_entered_by_every_rank(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_flags_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)   # a hang fails by timeout
+    r0, r1 = (torch.load(tmp_path / f"flags{r}.pt") for r in range(world))
+    assert r0 == r1
+    assert r0[0] == [True, True, True]            # written on ANY rank counts (the all-reduce delivers the gradient)
+    assert r0[1] == [True, True, False]           # skipped everywhere: Adamax leaves the parameter alone
+    assert r0[2] == [True, True, True]
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    """The gradient exchange split at a boundary (tail started early, head in step()) sums exactly what ONE all-reduce
+    of the whole buffer sums."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import FlatTrainer
+        torch.manual_seed(1)
+        head = S.BlockGen(2, [S.Conv(8, 3, 2), S.Norm(), S.LIF()])
+        tail = S.BlockGen(8, [S.Conv(4, 1), S.Conv(6, 3)])
+        model = torch.nn.ModuleList([head, tail])
+        tr = FlatTrainer(model, lr=1e-3)
+        lo = tr.overlap_from([tail])
+        assert lo == sum(p.numel() for p in head.parameters())
+        with pytest.raises(RuntimeError):
+            tr.overlap_from([head])               # not the tail of the parameter order
+        g = torch.Generator().manual_seed(7 + rank)
+        local = torch.randn(tr.flat_grad.shape, generator=g)
+        tr.flat_grad.copy_(local)
+        tr.early_all_reduce()                     # what the backward hook does at the boundary
+        assert tr._early_work is not None
+        tr.early_all_reduce()                     # a second hook call in the same pass is a no-op
+        tr.all_reduce()                           # step(): the rest + join
+        assert tr._early_work is None
+        whole = local.clone()
+        dist.all_reduce(whole)
+        torch.save({"split": tr.flat_grad.clone(), "whole": whole}, os.path.join(out_dir, f"ov{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_split_gradient_exchange_equals_one_allreduce(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(tmp_path / f"ov{r}.pt")
+        assert torch.equal(d["split"], d["whole"])
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_starts_two_ranks(tmp_path):
+    """``python bench.py --gpus 2`` without a launcher must run TWO ranks (it used to measure one GPU and print n_gpus 1);
+    ``--dry-run`` rehearses launch, rendezvous and one collective without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNN_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                         # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"]["world_size"] == 2 and out["dist"]["ranks_in_allreduce"] == 2
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr

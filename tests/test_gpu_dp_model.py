@@ -135,3 +135,49 @@ def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, s
                 assert rel_err(v, ref_sd[k]) < 1e-5, k
             else:
                 assert int(v) == int(ref_sd[k]) == T, k
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm
+        from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters
+        torch.manual_seed(3)
+        blk = BlockGen(2, [Conv(8, 3), Norm(), LIF(), Conv(8, 1)]).cuda().train()
+        extra = BlockGen(8, [Conv(4, 1)]).cuda()
+        model = torch.nn.ModuleList([blk, extra])
+        tr = FlatTrainer(model, lr=1e-2)
+        broadcast_parameters(tr)
+        x = synthetic_events(3, 2, 12, 16, p=0.3, seed=rank).cuda()
+        w_extra = extra.net[0][0].weight
+        start = w_extra.detach().clone()
+        for it in range(2):
+            tr.zero_grad()
+            if rank == 0 and it == 0:            # ONLY rank 0 produces a gradient for `extra`, and only in step 0
+                w_extra.grad = torch.ones_like(w_extra)
+            out, _ = blk(x)
+            out.square().mean().backward()
+            tr.step()                             # must not hang: every rank enters the same collectives
+        torch.cuda.synchronize()
+        torch.save({"extra": w_extra.detach().cpu(), "start": start.cpu(), "flat": tr.flat_param.detach().cpu(),
+                    "steps": list(tr.param_steps)}, os.path.join(out_dir, f"uneven{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_parameter_written_on_one_rank_only_does_not_hang_the_step(tmp_path, hip_lib):
+    """Rank 1 has no gradient for a parameter rank 0 wrote: the written-flag exchange used to sit behind a rank-local
+    condition (rank 0 skipped the collective rank 1 waited in).  Now both ranks finish, the parameter moves by the
+    AVERAGED gradient on both (written on ANY rank counts) in step 0 and stays put in step 1."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    world, port = 2, _free_port()
+    mp.spawn(_uneven_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"uneven{k}.pt") for k in range(world))
+    assert torch.equal(r0["flat"], r1["flat"])                       # replicas stayed together
+    assert not torch.equal(r0["extra"], r0["start"])                 # the one-rank gradient arrived everywhere
+    assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 1 and r0["steps"][0] == 2
+    # Adamax, first step, gradient 1/2 (ones averaged over two ranks): the update is lr * sign = 1e-2 exactly-ish
+    assert torch.allclose(r0["start"] - r0["extra"], torch.full_like(r0["start"], 1e-2), rtol=1e-4, atol=0)

@@ -40,15 +40,35 @@ def test_tiny_yolo_train_step_with_padded_labels_matches_oracle(S):
     _train_step_vs_oracle(S, 4, 2, 32, 48, pad_rows=2)
 
 
-def _train_step_vs_oracle(S, T, B, H, W, pad_rows=0):
-    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
+def test_tiny_yolo_train_step_with_random_start_time_matches_oracle(S):
+    """The reference's default ``time_window: 16`` (config/config.yaml:8): ``training_step`` drops a random prefix
+    ``r in [0, 16)`` of the sequence, drawn with ``torch.randint(..., dtype=torch.uint32)`` from the global generator
+    (models/soda.py:146-158, 246-257).  Product and oracle seeded alike must drop the SAME prefix and agree on the
+    loss and every gradient; several seeds so that different prefix lengths (incl. 0) are exercised."""
+    seen = set()
+    for seed in (0, 1, 5):
+        torch.manual_seed(seed)
+        r = int(torch.randint(0, 16, (1,), requires_grad=False, dtype=torch.uint32))
+        seen.add(r)
+        _train_step_vs_oracle(S, 20, 2, 32, 48, time_window=16, draw_seed=seed, expect_T=20 - r)
+    assert len(seen) >= 2
+
+
+def _train_step_vs_oracle(S, T, B, H, W, pad_rows=0, time_window=0, draw_seed=None, expect_T=None):
+    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=time_window)
     X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B, pad_rows=pad_rows)
     product.train()
     oracle.train()
+    if draw_seed is not None:
+        torch.manual_seed(draw_seed)
     loss_ref = oracle.training_step((X, labels))
     loss_ref.backward()
+    if draw_seed is not None:
+        torch.manual_seed(draw_seed)
     loss = product.training_step((X.cuda(), labels.cuda()))
     loss.backward()
+    if expect_T is not None:
+        T = expect_T
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
     ref_grads = dict(oracle.named_parameters())
     worst = 0.0

@@ -125,3 +125,31 @@ def test_conv_lstm_matches_reference_vectors(S, golden_dir):
             h, state = cell(x[t].detach(), state)
             cs.append(state[1])
     assert rel_err(torch.stack(cs), torch.from_numpy(z["c"])) < 1e-5
+
+
+def test_sli_layer_matches_reference_generated_vectors(S, golden_dir):
+    """HIP ``SLI()`` layer against outputs of the reference's own ``sli_feed_forward_step`` (tests/golden/sli.npz,
+    written by make_golden.py from models/modules/sli.py:110-126)."""
+    from snn_for_object_detection_amd import BlockGen, SLI
+    z = np.load(os.path.join(golden_dir, "sli.npz"))
+    x = torch.from_numpy(z["x"]).cuda().requires_grad_()
+    blk = BlockGen(x.shape[2], [SLI()]).cuda()
+    out, st = blk(x)
+    ((out * torch.from_numpy(z["gv"]).cuda()).sum() + (st[0][-1].i * torch.from_numpy(z["gi"]).cuda()).sum()).backward()
+    assert rel_err(out, torch.from_numpy(z["v"])) < 1e-6
+    assert rel_err(st[0][-1].i, torch.from_numpy(z["i_final"])) < 1e-6
+    assert rel_err(x.grad, torch.from_numpy(z["gx"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["s0", "s07"])
+def test_synapse_layer_matches_reference_generated_vectors(S, golden_dir, tag):
+    """HIP ``Synapse`` cell against outputs of the reference's own ``synapse_feed_forward_step``
+    (tests/golden/synapse.npz, from models/modules/synapse.py:73-103)."""
+    from snn_for_object_detection_amd.layer_gen import SynapseCell
+    z = np.load(os.path.join(golden_dir, "synapse.npz"))
+    x = torch.from_numpy(z["x"]).cuda().requires_grad_()
+    out, st = SynapseCell(dt=float(z["dt"]), sigma_inhibition=float(z[f"sigma_{tag}"])).cuda()(x)
+    (out * torch.from_numpy(z["gg"]).cuda()).sum().backward()
+    assert rel_err(out, torch.from_numpy(z[f"g_{tag}"])) < 1e-6
+    assert rel_err(st.p, torch.from_numpy(z[f"p_final_{tag}"])) < 1e-6
+    assert rel_err(x.grad, torch.from_numpy(z[f"gx_{tag}"])) < 1e-5

@@ -592,6 +592,34 @@ def test_last_step_only_lif_long_sequence_in_segments(HF):
     assert res[0][0].sum() > 0 and res[0][1].abs().sum() > 0
 
 
+def test_last_step_only_never_takes_the_checkpointed_scan(HF):
+    """``last_only`` allocates ONE step of output; the checkpointed LIF kernels write / read all T of them, so the
+    memory lever must not apply (it used to: an out-of-bounds write of (T-1)*M*C floats).  Same bits with the lever set
+    as without."""
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.layer_gen import HipBatchNorm2d
+    torch.manual_seed(29)
+    T, B, C, H, W = 12, 2, 32, 7, 9
+    x = torch.randn(T, B, C, H, W, device="cuda") * 2
+    g_last = torch.randn(B, C, H, W, device="cuda")
+    res = []
+    for lever in (0, None):
+        HF.LIF_CHECKPOINT_BYTES = lever          # 0 = every LIF layer, None = never
+        try:
+            bn = HipBatchNorm2d(C).cuda().train()
+            xin = x.clone().requires_grad_()
+            guard = torch.full((4 * T * B * C * H * W,), 7.0, device="cuda")   # neighbours of the small output buffer
+            out, st = HF.affine_neuron(xin, _hip.NEURON_LIF, None, bn=bn, last_only=True)
+            assert out.shape == (B, C, H, W)
+            out.backward(g_last)
+            assert bool((guard == 7.0).all())
+            res.append((out.detach(), xin.grad, bn.weight.grad, st.v.detach(), st.i.detach()))
+        finally:
+            HF.LIF_CHECKPOINT_BYTES = None
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tanh", [True, False])
 def test_last_step_only_scan_equals_the_full_scan(HF, tanh):
     """SNN_SCAN_LAST_STEP_ONLY (the detection head keeps the last timestep only): the [B,C,H,W] output equals the last

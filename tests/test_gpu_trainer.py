@@ -239,3 +239,100 @@ def test_parameters_without_gradient_are_left_alone(S):
     model.float().cpu()
     with pytest.raises(RuntimeError, match="flat parameter buffer"):
         tr.step()
+
+
+def test_cached_weight_images_follow_the_parameter_not_the_trainer(S):
+    """The pre-split / transposed weight images are tensor VIEWS kept on the parameter: when the trainer is dropped and
+    the allocator recycles memory, an eval forward still reads valid images (they used to be raw addresses into buffers
+    only the trainer kept alive - a use-after-free with silently wrong convolution outputs).  A second trainer clears
+    what the first one left."""
+    import gc
+    from snn_for_object_detection_amd import functional as HF
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 3, 2, 32, 48
+    X, labels = synthetic_events(T, B, H, W, p=0.1).cuda(), synthetic_labels(B).cuda()
+    torch.manual_seed(2)
+    m = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    tr = FlatTrainer(m, lr=1e-3)
+    tr.zero_grad()
+    m.training_step((X, labels)).backward()
+    tr.step()
+    torch.cuda.synchronize()
+    conv_w = next(p for p in m.parameters() if p.dim() == 4 and p.shape[1] > 2)
+    assert not hasattr(conv_w, "_snn_w16_ptr") and isinstance(conv_w._snn_w16, torch.Tensor)
+    del tr
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(16)]   # recycle whatever was freed
+    m.eval()
+    with torch.no_grad():
+        _, cls_a, box_a = m(X)
+        HF.USE_PRESPLIT_WEIGHTS = False          # the same forward converting the weights in every block
+        try:
+            _, cls_b, box_b = m(X)
+        finally:
+            HF.USE_PRESPLIT_WEIGHTS = True
+    assert torch.isfinite(cls_a).all() and torch.equal(cls_a, cls_b) and torch.equal(box_a, box_b)
+    del junk
+    # a new trainer starts from a clean slate: no image of the old one survives on the parameters
+    m.train()
+    tr2 = FlatTrainer(m, lr=1e-3)
+    assert conv_w._snn_w16.untyped_storage().data_ptr() == tr2.flat_w16.untyped_storage().data_ptr()
+    assert not hasattr(conv_w, "_snn_wt16") or tr2.flat_wt16 is not None
+
+
+def test_skipped_parameters_keep_their_own_step_count_like_torch(S):
+    """torch.optim.Adamax keeps ``step`` per parameter and leaves it alone for a parameter without a gradient, so the
+    bias correction of a parameter that skipped steps differs from the others'.  Same model, same gradients: the fused
+    trainer and torch.optim.Adamax must stay together, and their state_dicts must be interchangeable."""
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+
+    def build():
+        torch.manual_seed(3)
+        blk = BlockGen(2, [Conv(8, 3), Norm(), LIF(), Conv(8, 1)]).cuda().train()
+        extra = BlockGen(8, [Conv(4, 1)]).cuda()
+        never = BlockGen(8, [Conv(2, 1)]).cuda()             # never receives a gradient
+        return torch.nn.ModuleList([blk, extra, never]), blk, extra
+
+    ma, blk_a, extra_a = build()
+    mb, blk_b, extra_b = build()
+    tr = FlatTrainer(ma, lr=1e-2)
+    opt = torch.optim.Adamax(list(mb.parameters()), lr=1e-2)
+    x = synthetic_events(3, 2, 12, 16, p=0.3).cuda()
+    g_extra = torch.randn(extra_a.net[0][0].weight.shape, device="cuda")
+    for it in range(5):
+        tr.zero_grad()
+        opt.zero_grad(set_to_none=True)
+        if it in (1, 4):                                     # `extra` gets a gradient in steps 1 and 4 only
+            extra_a.net[0][0].weight.grad = g_extra.clone() * (it + 1)
+            extra_b.net[0][0].weight.grad = g_extra.clone() * (it + 1)
+        for blk in (blk_a, blk_b):
+            out, _ = blk(x)
+            out.square().mean().backward()
+        tr.step()
+        opt.step()
+        for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            assert rel_err(pa, pb) < 1e-5, (it, n)
+    assert tr.step_count == 5
+    k_extra = [i for i, p in enumerate(tr.params) if p is extra_a.net[0][0].weight][0]
+    assert tr.param_steps[k_extra] == 2 and tr.param_steps[0] == 5 and tr.param_steps[-1] == 0
+    sd, sd_t = tr.state_dict(), opt.state_dict()
+    assert set(sd["state"]) == set(sd_t["state"])           # the never-updated parameter has no entry, as in torch
+    for k in sd["state"]:
+        assert float(sd["state"][k]["step"]) == float(sd_t["state"][k]["step"])
+        assert rel_err(sd["state"][k]["exp_avg"], sd_t["state"][k]["exp_avg"]) < 1e-5
+        assert rel_err(sd["state"][k]["exp_inf"], sd_t["state"][k]["exp_inf"]) < 1e-5
+    # torch's state (differing per-parameter steps) loads into a fresh fused trainer and continues identically
+    mc, blk_c, extra_c = build()
+    mc.load_state_dict(mb.state_dict())
+    tr_c = FlatTrainer(mc, lr=1.0)
+    tr_c.load_state_dict(sd_t)
+    assert tr_c.param_steps == tr.param_steps
+    for model, blk, stepper in ((mb, blk_b, opt), (mc, blk_c, tr_c)):
+        stepper.zero_grad()
+        out, _ = blk(x)
+        out.square().mean().backward()
+        stepper.step()
+    for (n, pb), pc in zip(mb.named_parameters(), mc.parameters()):
+        assert rel_err(pc, pb) < 1e-5, n

@@ -78,3 +78,55 @@ def test_tiny_yolo_layer_census():
     assert convs.count((512, 256, 1, 1)) == 1 and convs.count((320, 128, 1, 1)) == 1
     assert convs.count((256, 36, 1, 1)) == 3 and convs.count((256, 27, 1, 1)) == 3
     assert sum(1 for c in convs if c[2] == 3) == 19 and sum(1 for c in convs if c[2] == 1) == 29
+
+
+def test_oracle_sli_matches_reference_vectors(golden_dir):
+    """``sli.npz``: the reference's own ``sli_feed_forward_step`` (models/modules/sli.py:110-126) over a seeded
+    sequence - the in-tree witness of norse's LI step ordering, pinned as data."""
+    z = np.load(os.path.join(golden_dir, "sli.npz"))
+    x = torch.from_numpy(z["x"]).requires_grad_()
+    cell = ON.SLICell(dt=float(z["dt"]))
+    state, vs = None, []
+    for t in range(x.shape[0]):
+        v, state = cell(x[t], state)   # state None at t = 0: the oracle builds SLICell.initial_state (0-dim v, zero i)
+        vs.append(v)
+    vs = torch.stack(vs)
+    assert torch.equal(vs.detach(), torch.from_numpy(z["v"]))
+    assert torch.equal(state[1].detach(), torch.from_numpy(z["i_final"]))
+    ((vs * torch.from_numpy(z["gv"])).sum() + (state[1] * torch.from_numpy(z["gi"])).sum()).backward()
+    assert torch.allclose(x.grad, torch.from_numpy(z["gx"]), rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_li_step_is_the_sli_step_without_the_gate(golden_dir):
+    """The LI restatement (oracle/neurons.py, norse absent) against the reference-generated SLI vectors: with the
+    saturation gate forced to 1 the SLI step IS norse's LI step (sli.py:110-126 vs SURVEY 8a-7), so feeding the LI
+    restatement the gated inputs ``x * sigmoid(v_st - |v_prev|)`` recorded from the fixture must reproduce the fixture's
+    potentials bit for bit - this pins the LI ordering (current jump first) and constants on reference data."""
+    from oracle import neurons as NE
+    z = np.load(os.path.join(golden_dir, "sli.npz"))
+    x, v_ref = torch.from_numpy(z["x"]), torch.from_numpy(z["v"])
+    state = None
+    v_prev = torch.zeros_like(x[0])
+    for t in range(x.shape[0]):
+        gated = x[t] * torch.sigmoid(torch.as_tensor(1.0) - torch.abs(v_prev))
+        v, state = NE.LICell(dt=float(z["dt"]))(gated, state)
+        assert torch.equal(v.detach(), v_ref[t])
+        v_prev = v.detach()
+    assert torch.equal(state.i.detach(), torch.from_numpy(z["i_final"]))
+
+
+def test_oracle_synapse_matches_reference_vectors(golden_dir):
+    """``synapse.npz``: ``synapse_feed_forward_step`` (models/modules/synapse.py:73-103), sigma = 0 and 0.7."""
+    z = np.load(os.path.join(golden_dir, "synapse.npz"))
+    for tag in ("s0", "s07"):
+        x = torch.from_numpy(z["x"]).clone().requires_grad_()
+        cell = ON.SynapseCell(dt=float(z["dt"]), sigma_inhibition=float(z[f"sigma_{tag}"]))
+        state, gs = None, []
+        for t in range(x.shape[0]):
+            g, state = cell(x[t], state)
+            gs.append(g)
+        gs = torch.stack(gs)
+        assert torch.equal(gs.detach(), torch.from_numpy(z[f"g_{tag}"]))
+        assert torch.equal(state[0].detach(), torch.from_numpy(z[f"p_final_{tag}"]))
+        (gs * torch.from_numpy(z["gg"])).sum().backward()
+        assert torch.allclose(x.grad, torch.from_numpy(z[f"gx_{tag}"]), rtol=1e-6, atol=1e-7)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel clock of the implicit-GEMM convolution under its own load (MI355X lowers its clock under MFMA load: the
 nominal peaks are quoted at 2.4 GHz).  Needs the -DSNN_CLOCK build: python -m snn_for_object_detection_amd._build --clock,
-SNN_HIP_LIB=snn_for_object_detection_amd/libsnn_hip_clock.so.
+SNN_HIP_LIB=build/libsnn_hip_clock.so.
 usage: clock_conv.py fwd|dgrad Cin Cout k s H W [frames] [seconds]
 Every block stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at its begin and end; after >= `seconds` of
 back-to-back launches on random data the clock is delta(cycles) / delta(10 ns ticks) x 100 MHz, median over blocks."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase breakdown of k_conv_wgrad_halo from in-kernel cycle stamps (needs the -DSNN_TUNING library:
-SNN_HIP_LIB=.../libsnn_hip_tuning.so).  usage: halo_stamps.py N H W Cin Cout stride"""
+SNN_HIP_LIB=build/libsnn_hip_tuning.so).  usage: halo_stamps.py N H W Cin Cout stride"""
 import ctypes
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time snn_conv2d_wgrad (kernel + ordered slab reduce) on the 3x3 layer shapes of TinyYolo GEN1 B=5 T=32 (and the
-deep-12 / 1 Mpx shapes with --all).  With a -DSNN_TUNING library (SNN_HIP_LIB=.../libsnn_hip_tuning.so) and
+deep-12 / 1 Mpx shapes with --all).  With a -DSNN_TUNING library (SNN_HIP_LIB=build/libsnn_hip_tuning.so) and
 SNN_WGRAD_NO_HALO=1 the same shapes run on the implicit-GEMM kernel for comparison."""
 import os
 import sys
