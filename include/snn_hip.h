@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 7
+#define SNN_ABI_VERSION 8
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -141,6 +141,30 @@ int snn_weight_presplit(const float* w, void* out, int64_t n, int precision, voi
  *   valid for SNN_PREC_FP16X3 (fwd) / SNN_PREC_BF16X3 (dgrad) only.  With it the kernels stop converting the weight
  *   tile in every block; the results are bit-identical to the conversion on the fly.  Shapes whose kernel cannot use
  *   it read `w` / `wt` as before, so both pointers are always passed. */
+/* ---- Halo-resident 3x3 / stride 1 / pad 1 convolution (csrc/conv_halo.hip): forward AND data gradient of the 64- and
+ * 128-channel layers (reference models/modules/layer_gen.py:129-136, nn.Conv2d(C, C', 3, padding=1, bias=False)).
+ * The activation halo of a tile is fetched and split into its 16-bit pieces once per 32-channel chunk (the implicit
+ * GEMM does both once per tap); the weights arrive by LDS-DMA from an image in MFMA-fragment order.
+ *   snn_conv3x3_halo_supported : 1 when the kernel covers the shape (Cin % 32 == 0, Cout % 64 == 0, W <= 78, ...);
+ *                                otherwise use snn_conv2d_fwd / snn_conv2d_dgrad.
+ *   snn_weight_frag_image_batched : builds the weight images of n layers in ONE launch.  table (device, int64) rows
+ *       {float offset of the layer's [O][3][3][I] matrix in flat_src, BYTE offset of its image in flat_dst, O, I}; an
+ *       image takes snn_weight_frag_image_bytes(O, I) = 9*O*I*4 bytes (as many as the weights); max_threads = the
+ *       largest 9 * (I/32) * (O/32) * 128 of the table.  Forward: src = the OHWI weights, flip = 0, SNN_PREC_FP16X3.
+ *       Data gradient: src = the transposed weights [Cin][KH][KW][Cout] (snn_weight_transpose), flip = 1 (mirrored
+ *       taps), SNN_PREC_BF16X3.  Redo after every optimiser step.
+ *   snn_conv3x3_halo : y[N][H][W][ldy] = conv3x3(x[N][H][W][ldx], image) (+ addend + addend2), Cin input and Cout output
+ *       channels (for a data gradient: x = dy, "Cin" = the layer's Cout and vice versa).  precision = the image's.
+ *       bn_partial / frames_per_step / bn_layout as for snn_conv2d_fwd (forward arithmetic only, no addend); the partials
+ *       hold snn_conv2d_fwd_bn_partial_size() doubles, bn_layout[0] = snn_conv3x3_halo_bn_chunks(), bn_layout[1] = 0. */
+int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int Cout);
+int64_t snn_conv3x3_halo_bn_chunks(int frames_per_step, int H, int W);
+size_t snn_weight_frag_image_bytes(int O, int I);
+int snn_weight_frag_image_batched(const float* flat_src, void* flat_dst, const int64_t* table, int n, int max_threads,
+                                  int flip, int precision, void* stream);
+int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image, float* y, int64_t ldy, int64_t N, int H, int W,
+                     int Cin, int Cout, const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2,
+                     double* bn_partial, int frames_per_step, int* bn_layout, int precision, void* stream);
 size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step, int Ho, int Wo, int Cout);
 int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const void* w_split, float* y, int64_t ldy,
                    int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout,

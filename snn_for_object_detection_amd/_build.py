@@ -98,7 +98,7 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, stam
         spath = os.path.join(CSRC, src)
         opath = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(opath)
-        key = _sha(open(spath, "rb").read(), header_bytes, " ".join(FLAGS).encode(), cc.encode())
+        key = _sha(open(spath, "rb").read(), header_bytes, " ".join(FLAGS[:-1]).encode(), cc.encode())  # (no -I path)
         if force or not os.path.exists(opath) or _read_stamp(opath + ".buildstamp").get("key") != key:
             jobs.append(([hipcc, *FLAGS, "-c", spath, "-o", opath], opath, key))
 

@@ -1,0 +1,518 @@
+// Halo-resident 3x3 / stride 1 / pad 1 convolution for the 64- and 128-channel layers, forward AND data gradient,
+// on the gfx950 matrix cores with 16-bit split products (fp16 x 3 forward, bf16 x 3 backward; fp32 storage and
+// accumulation, same arithmetic per product as conv.hip's k_conv_gather).
+//
+// Replaces nn.Conv2d(C, C', 3, padding=1, bias=False) forward and its data gradient (reference
+// models/modules/layer_gen.py:129-136) for the layer-major schedule.  The data gradient is the SAME kernel: dx is a
+// 3x3 convolution of dy with the mirrored taps of w^T, and the mirroring / transposition live in the weight image
+// (snn_weight_frag_image, flip = 1, built from the [Cin][KH][KW][Cout] transpose).
+//
+// Why a second kernel.  The implicit GEMM (k_conv_gather) fetches one shifted copy of the activation tile PER TAP and
+// splits it into its 16-bit pieces each time - nine fetches through L1 and nine conversions of every element - and
+// pays two barriers per 32-deep k-step; its matrix pipe is 23-33 % busy (profiles/r02_pmc_mfma_gen1.txt).  Here:
+//   * PADDED-STRIP pixel order.  All images are laid end to end as rows of PW = W + 1 cells with ONE zero cell after
+//     every image row and ONE zero row after every image: (row y, column -1) and (row y-1, column W) are the same
+//     zero cell, so tap (kh, kw) of cell s is cell s + (kh-1)*PW + (kw-1) - no border masks anywhere.  A block owns
+//     128 consecutive strip cells (their outputs; pad cells are computed and dropped: W*H / ((W+1)*(H+1)) of the
+//     work is useful, 94 % at 30x38, 97 % at 60x76) and needs the 128 + 2*PW + 2 cells around them.
+//   * A operand: per 32-channel chunk that halo is fetched ONCE (raw buffer loads spread over the nine taps of the
+//     previous chunk, out-of-image cells by the hardware range check), split ONCE into its two 16-bit pieces and
+//     written to LDS as [piece][cell][32 ch] (64-byte cells, 16-byte slots XOR-swizzled with (cell >> 2) & 3: a
+//     ds_read_b128 lane group always covers 16 cells that are distinct modulo 16, hence all 64 banks once).  The nine
+//     taps read that image at nine cell offsets.
+//   * B operand: the weights are pre-arranged ONCE per optimiser step in exactly the order the MFMA fragments are
+//     read - [tap][32-ci chunk][32-co tile][k16][piece][lane] x 16 bytes (snn_weight_frag_image) - so a k-step's
+//     tile is one contiguous 4 KiB x (CO/32) block that goes global -> LDS by LDS-DMA (global_load_lds, no registers,
+//     no VALU) one k-step ahead into a double buffer, and every fragment read is lane-linear (conflict-free).
+//   * one barrier per k-step of 24 MFMAs per wave; the only VALU in the loop is the fragment address arithmetic.
+// Epilogue as in k_conv_gather: accumulators transposed through LDS, 16-byte stores, up to two fused addends
+// (gradient accumulation), BatchNorm statistics partials of the stored values (forward).
+#include "snn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int HBM_ = 128;               // strip cells (GEMM rows) per block
+constexpr int HCELLS = 288;             // halo cells staged per chunk (9 passes of 32): PW <= 79
+constexpr int HPIECE = HCELLS * 64;     // bytes of one piece image [cell][32 ch] x 16 bit
+constexpr int NPASS = HCELLS / 32;      // == taps: one staging pass is requested during every tap of the previous chunk
+static_assert(NPASS == 9, "one halo staging pass per tap");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kF16WeightScale = 256.0f;   // the fp16 x 3 pre-scales of conv.hip (exact powers of two)
+constexpr float kF16ActScale = 16.0f;
+constexpr float kF16Unscale = 1.0f / (kF16WeightScale * kF16ActScale);
+
+struct HaloGeom {
+    int64_t ldx, ldy, ld_add, ld_add2;
+    int N, H, W, Cin, Cout;
+    int PW, PH;                 // strip row pitch (W + 1) and rows per image (H + 1)
+    int G;                      // images per group: tiles do not cross groups (= frames per timestep with statistics)
+    int group_cells;            // G * PH * PW
+    int tiles_per_group, tiles, tiles_per_xcd, ntiles_n;
+    unsigned magic_pw, magic_ph;   // ceil(2^32 / d): q = umulhi(n, magic) for n * d < 2^32 (small n only)
+    int out_vec;
+    double* bn_partial;         // forward statistics partials [t][c][chunk][2] (null: none); chunk = tile of the group
+};
+
+__device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+
+// two 16-bit pieces of four fp32 values: fp16 (x * 2^4 = h + l) or bf16 (x = h + l); same arithmetic as conv.hip
+template <bool F16>
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        if constexpr (F16) {
+            const float a = v[e] * kF16ActScale, b = v[e + 1] * kF16ActScale;
+            const f16x2 ph = __builtin_convertvector(f32x2{a, b}, f16x2);   // RNE; out of range -> inf (loud)
+            const f16x2 pl = __builtin_convertvector(f32x2{a - (float)ph[0], b - (float)ph[1]}, f16x2);
+            hi[e >> 1] = __builtin_bit_cast(unsigned, ph);
+            lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+        } else {
+            f32x2 rest = {v[e], v[e + 1]};
+            const bf16x2 ph = __builtin_convertvector(rest, bf16x2);
+            const unsigned bits = __builtin_bit_cast(unsigned, ph);
+            rest[0] -= __builtin_bit_cast(float, bits << 16);
+            rest[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+            const bf16x2 pl = __builtin_convertvector(rest, bf16x2);
+            hi[e >> 1] = bits;
+            lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+        }
+    }
+}
+
+// byte offset of the 16-byte slot `slot` (0..3 = channels 8*slot .. 8*slot+7) of halo cell `cell` inside a piece image
+__device__ __forceinline__ int cell_slot_off(int cell, int slot) { return cell * 64 + ((slot ^ ((cell >> 2) & 3)) << 4); }
+
+// CO: output channels per block (64 | 128); F16: fp16 pieces (forward) or bf16 pieces (data gradient).
+// 4 waves as 2 x 2: a wave owns 64 cells x CO/2 channels (TM = 2 row tiles, TN = CO/64 column tiles of 32 x 32).
+template <int CO, bool F16>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
+                                                           const unsigned char* __restrict__ wimg,
+                                                           float* __restrict__ y, HaloGeom g,
+                                                           const float* __restrict__ addend,
+                                                           const float* __restrict__ addend2) {
+    constexpr int WM = 2, WN = 2, TM = 2, TN = CO / 64;
+    constexpr int BTILE = (CO / 32) * 4096;     // bytes of one k-step's weight tile
+    constexpr int NDMA = (CO / 32) * 4 / 4;     // 1-KiB LDS-DMA pieces per wave and k-step
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE];   // ONE array: 52 / 68 KiB
+    unsigned char* Aimg = smem;                        // [2 pieces][HCELLS][64 B]
+    unsigned char* Bimg = smem + 2 * HPIECE;           // [2 buffers][BTILE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware order: ids b, b + 8, ... share an XCD (its own L2); XCD q walks the q-th contiguous run of tiles, so
+    // neighbouring tiles - whose halos overlap by 2*PW + 2 cells - meet in one L2
+    const int bq = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) * g.tiles_per_xcd + bq / g.ntiles_n;
+    if (tile >= g.tiles) return;   // padding block of the last XCD share (whole block, before any barrier)
+    const int n0c = (bq % g.ntiles_n) * CO;                     // first output channel of this block
+    const int grp = tile / g.tiles_per_group, kt = tile - grp * g.tiles_per_group;
+    const int c0 = kt * HBM_;                                   // first cell of the tile inside its group
+    const int R0g = c0 / g.PW, x0 = c0 - R0g * g.PW;            // its strip row inside the group, its column
+    const int ng = R0g / g.PH, y0 = R0g - ng * g.PH;
+    const int n0 = grp * g.G + ng;                              // image of the tile's first cell
+    const int nb = n0 > 0 ? n0 - 1 : 0;                         // base image of the buffer resource
+
+    // ---- halo loader: thread (cell = pass * 32 + tid / 8, channel quad = tid % 8)
+    const int quad = tid & 7;
+    const int64_t ipix = (int64_t)g.H * g.W;
+    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * 4;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (int64_t)nb * ipix * g.ldx), 0, xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+    unsigned voff[NPASS];
+    int awr[NPASS];      // LDS byte offset (inside a piece) this thread writes for pass p
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int cell = p * 32 + (tid >> 3);
+        // cell c of the halo is strip cell (tile start) + c - PW - 1; counted from column 0 of strip row R0 - 2:
+        const unsigned u = (unsigned)(x0 + cell + g.PW - 1);
+        const unsigned dR = udiv_small(u, g.magic_pw);
+        const int xx = (int)(u - dR * g.PW);
+        // ... and from row 0 of image n0 - 1:
+        const unsigned v = (unsigned)(y0 + (int)dR + g.PH - 2);
+        const unsigned dn = udiv_small(v, g.magic_ph);
+        const int yy = (int)(v - dn * g.PH);
+        const int n = n0 - 1 + (int)dn;
+        const bool ok = n >= 0 && n < g.N && xx < g.W && yy < g.H;
+        const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
+        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;   // >= 2 GiB: range check -> zeros
+        awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
+    }
+
+    // ---- fragment addressing
+    int cellbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) cellbase[i] = g.PW + 1 + (wm * TM + i) * 32 + r;
+    const int nchunks = g.Cin >> 5;
+    const int co_tiles = g.Cout >> 5;
+    // weight image: [tap][chunk][co tile][k16][piece][lane] x 16 B; this wave copies pieces wave, wave + 4, ...
+    const unsigned char* wsrc = wimg + (int64_t)(n0c >> 5) * 4096 + lane * 16;
+    // LDS-DMA in inline asm: hipcc's wait-count bookkeeping turns conservative around the builtin (it drains vmcnt(0)
+    // before every reuse of a load register, i.e. right behind the DMA it should leave in flight); hidden from it, the
+    // compiler counts only its own loads - which errs on the early side - and the DMA's completion is counted by hand
+    // (the vmcnt of the k-step's closing statement).  M0 (the LDS destination) is written in the statement that uses it.
+    const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bimg;
+    auto dma_b = [&](int kk, int buf) {   // kk = chunk * 9 + tap
+        const int chunk = kk / 9, tap = kk - chunk * 9;
+        const unsigned char* src = wsrc + ((int64_t)(tap * nchunks + chunk) * co_tiles) * 4096 + wave * 1024;
+        const unsigned dst = lds_b + buf * BTILE + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + q * 4096), "s"(__builtin_amdgcn_readfirstlane(dst + q * 4096))
+                         : "memory");
+        }
+    };
+
+    f32x4 pf[NPASS];
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            u32x2 hi, lo;
+            split4<F16>(pf[p], hi, lo);
+            *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
+            *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto kstep = [&](int tapoff, const unsigned char* Bb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // lane (r, h) holds k = 16*ks + 8*h .. +7 of its row
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = cell_slot_off(cellbase[i] + tapoff, 2 * ks + h);
+                ah[i] = *reinterpret_cast<const bf16x8*>(Aimg + off);
+                al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = (wn * TN + j) * 4096 + ks * 2048 + lane * 16;
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bb + off);
+                bl[j] = *reinterpret_cast<const bf16x8*>(Bb + off + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {   // small terms first
+                    if constexpr (F16) {
+                        const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]), xal = __builtin_bit_cast(f16x8, al[i]);
+                        const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // ---- prologue: halo of chunk 0 and the first weight tile
+    dma_b(0, 0);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+        pf[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[p], 0, 0));
+    store_halo();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int nk = nchunks * 9;
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        const int cbytes = (chunk + 1) * 128;   // channel offset of the NEXT chunk
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kk = chunk * 9 + tap;
+            const int cur = kk & 1;
+            // the other buffer was read during the previous k-step (every wave has passed that step's barrier)
+            if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // one staging pass of the next chunk's halo per tap: it is YOUNGER than this step's LDS-DMA, so the
+            // counted wait below leaves it in flight for a whole k-step (out-of-range offsets when there is no next chunk)
+            pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            kstep((kh - 1) * g.PW + (kw - 1), Bimg + cur * BTILE);
+            // this wave's share of the next weight tile has landed (all but the youngest vector-memory operation are
+            // done); the barrier makes every wave's share visible and retires this step's reads of the current buffer
+            // (lgkmcnt(0): this wave's fragment reads have really left the LDS before another wave may overwrite them)
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (more) {   // every wave is past its last read of this chunk's halo image: swap in the next one
+            store_halo();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- epilogue: transpose the accumulators through LDS (operand images are dead), 16 bytes per lane and store
+    constexpr int EW = TN * 32 + 4;    // staged row length in floats
+    constexpr int LPR = TN * 8;        // lanes per staged row (4 floats each)
+    constexpr int RPP = 64 / LPR;      // rows per pass
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
+    const bool ovec = g.out_vec != 0;
+    const int lrow = lane / LPR, c4 = (lane % LPR) * 4;
+    const int nch = n0c + wn * TN * 32 + c4;
+    const int cells_left = g.group_cells - c0;     // cells of the group from the tile start on
+    double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool stats = F16 && g.bn_partial != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = F16 ? acc[i][j][e] * kF16Unscale : acc[i][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: no barrier needed, only the LDS order
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+            const int row = pass * RPP + lrow;
+            const int m = (wm * TM + i) * 32 + row;            // cell of the tile
+            const unsigned u = (unsigned)(x0 + m);
+            const unsigned dR = udiv_small(u, g.magic_pw);
+            const int xx = (int)(u - dR * g.PW);
+            const unsigned v = (unsigned)(y0 + (int)dR);
+            const unsigned dn = udiv_small(v, g.magic_ph);
+            const int yy = (int)(v - dn * g.PH);
+            const int n = n0 + (int)dn;
+            const bool ok = m < cells_left && xx < g.W && yy < g.H && n < g.N && nch < g.Cout;
+            f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
+            if (!ok) continue;
+            const int64_t pix = ((int64_t)n * g.H + yy) * g.W + xx;
+            float* dst = y + pix * g.ldy + nch;
+            if (ovec) {
+                if (addend) val += *reinterpret_cast<const f32x4*>(addend + pix * g.ld_add + nch);   // fused accumulation
+                if (addend2) val += *reinterpret_cast<const f32x4*>(addend2 + pix * g.ld_add2 + nch);
+                *reinterpret_cast<f32x4*>(dst) = val;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float o = val[q];
+                    if (addend) o += addend[pix * g.ld_add + nch + q];
+                    if (addend2) o += addend2[pix * g.ld_add2 + nch + q];
+                    dst[q] = o;
+                }
+            }
+            if (stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double d = (double)val[q];
+                    ssum[q] += d;
+                    qsum[q] = fma(d, d, qsum[q]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (stats) {
+        // BatchNorm partials of the STORED values: lanes that share a channel quad (same lane % LPR) are added by
+        // shuffles, the two row waves through LDS - a fixed order, run to run
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                ssum[q] += __shfl_xor(ssum[q], o, 64);
+                qsum[q] += __shfl_xor(qsum[q], o, 64);
+            }
+        }
+        __syncthreads();   // every wave is done with its staging rows
+        double* red = reinterpret_cast<double*>(smem);   // [wave][LPR * 4 channels][2]
+        if (lane < LPR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                red[((wave * LPR + lane) * 4 + q) * 2 + 0] = ssum[q];
+                red[((wave * LPR + lane) * 4 + q) * 2 + 1] = qsum[q];
+            }
+        }
+        __syncthreads();
+        if (tid < CO) {   // channel n0c + tid: column wave wn = tid / (TN*32), both row waves in order
+            const int wn_ = tid / (TN * 32), cc = tid % (TN * 32);
+            double s = 0.0, q2 = 0.0;
+#pragma unroll
+            for (int wm_ = 0; wm_ < WM; ++wm_) {
+                const double* src = red + (((wm_ * WN + wn_) * LPR * 4) + cc) * 2;
+                s += src[0];
+                q2 += src[1];
+            }
+            if (n0c + tid < g.Cout) {
+                double* dstp = g.bn_partial + snn_bn_partial_index(grp, kt, n0c + tid, g.tiles_per_group, g.Cout);
+                dstp[0] = s;
+                dstp[1] = q2;
+            }
+        }
+    }
+}
+
+// ---- weight image in MFMA-fragment order.  src: [O][3][3][I] fp32 (the forward's OHWI weights, or the transposed
+// [Cin][KH][KW][Cout] matrix for the data gradient with flip = 1: tap t of the image is tap 8 - t of src).
+// image: [tap][I/32][O/32][k16 (2)][piece (2)][lane (64)] x 16 bytes; lane (r, h) holds src[o = 32*ot + r][tap][i = 32*ic +
+// 16*ks + 8*h .. + 7] as 8 hi pieces / 8 lo pieces.  One thread per (tap, ic, ot, ks, lane): two 16-byte loads, two stores.
+template <bool F16>
+__global__ void k_weight_frag_image(const float* __restrict__ flat_src, unsigned char* __restrict__ flat_dst,
+                                    const int64_t* __restrict__ table, int flip) {
+    // table row: {float offset of src in flat_src, byte offset of the image in flat_dst, O, I}
+    const int64_t* row = table + (int64_t)blockIdx.y * 4;
+    const float* src = flat_src + row[0];
+    unsigned char* dst = flat_dst + row[1];
+    const int O = (int)row[2], I = (int)row[3];
+    const int ot_n = O >> 5, ic_n = I >> 5;
+    const int64_t total = (int64_t)9 * ic_n * ot_n * 2 * 64;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const int ks = (int)((idx >> 6) & 1);
+        int64_t rest = idx >> 7;
+        const int ot = (int)(rest % ot_n); rest /= ot_n;
+        const int ic = (int)(rest % ic_n);
+        const int tap = (int)(rest / ic_n);
+        const int r = lane & 31, h = lane >> 5;
+        const int st = flip ? 8 - tap : tap;
+        const float* p = src + ((int64_t)(ot * 32 + r) * 9 + st) * I + ic * 32 + ks * 16 + h * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float a0 = e < 4 ? v0[e] : v1[e - 4], a1 = e < 4 ? v0[e + 1] : v1[e - 3];
+            if (F16) {
+                const float a = a0 * kF16WeightScale, b = a1 * kF16WeightScale;
+                const f16x2 ph = __builtin_convertvector(f32x2{a, b}, f16x2);
+                const f16x2 pl = __builtin_convertvector(f32x2{a - (float)ph[0], b - (float)ph[1]}, f16x2);
+                hi[e >> 1] = __builtin_bit_cast(unsigned, ph);
+                lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+            } else {
+                f32x2 rr = {a0, a1};
+                const bf16x2 ph = __builtin_convertvector(rr, bf16x2);
+                const unsigned bits = __builtin_bit_cast(unsigned, ph);
+                rr[0] -= __builtin_bit_cast(float, bits << 16);
+                rr[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+                const bf16x2 pl = __builtin_convertvector(rr, bf16x2);
+                hi[e >> 1] = bits;
+                lo[e >> 1] = __builtin_bit_cast(unsigned, pl);
+            }
+        }
+        unsigned char* o = dst + ((((int64_t)(tap * ic_n + ic) * ot_n + ot) * 2 + ks) * 2) * 1024 + lane * 16;
+        *reinterpret_cast<u32x4*>(o) = hi;
+        *reinterpret_cast<u32x4*>(o + 1024) = lo;
+    }
+}
+
+static unsigned magic_u32(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static bool halo_shape_ok(int64_t N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0) return false;
+    if (Cin % 32 != 0 || Cin < 32 || Cout % 64 != 0) return false;
+    if (W + 1 > 79) return false;                                  // halo of a 128-cell tile: 128 + 2*PW + 2 <= 288 cells
+    if (N * (int64_t)(H + 1) * (W + 1) >= 0x7fffffffLL) return false;   // strip cells of a group in 32 bits
+    return true;
+}
+
+}  // namespace
+
+extern "C" int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int Cout) {
+    return halo_shape_ok(N, H, W, Cin, Cout) ? 1 : 0;
+}
+
+// chunk slots per timestep of the statistics partials snn_conv3x3_halo writes (= its tiles per group)
+extern "C" int64_t snn_conv3x3_halo_bn_chunks(int frames_per_step, int H, int W) {
+    return snn_ceil_div((int64_t)frames_per_step * (H + 1) * (W + 1), HBM_);
+}
+
+extern "C" size_t snn_weight_frag_image_bytes(int O, int I) { return (size_t)9 * O * I * 4; }
+
+extern "C" int snn_weight_frag_image_batched(const float* flat_src, void* flat_dst, const int64_t* table, int n,
+                                             int max_groups, int flip, int precision, void* stream) {
+    SNN_REQUIRE(flat_src && flat_dst && table && n > 0 && max_groups > 0, "snn_weight_frag_image_batched: bad arguments");
+    SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3,
+                "snn_weight_frag_image: precision must be SNN_PREC_FP16X3 (forward) or SNN_PREC_BF16X3 (data gradient)");
+    SNN_REQUIRE(aligned16(flat_src) && aligned16(flat_dst), "snn_weight_frag_image: buffers must be 16-byte aligned");
+    int64_t bx = snn_ceil_div(max_groups, kThreads);
+    if (bx > 64) bx = 64;
+    dim3 grid((unsigned)bx, (unsigned)n);
+    if (precision == SNN_PREC_FP16X3)
+        hipLaunchKernelGGL(k_weight_frag_image<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, flat_src,
+                           static_cast<unsigned char*>(flat_dst), table, flip);
+    else
+        hipLaunchKernelGGL(k_weight_frag_image<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, flat_src,
+                           static_cast<unsigned char*>(flat_dst), table, flip);
+    SNN_CHECK_LAUNCH("snn_weight_frag_image_batched");
+    return 0;
+}
+
+extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image, float* y, int64_t ldy, int64_t N, int H,
+                                int W, int Cin, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
+                                int64_t ld_addend2, double* bn_partial, int frames_per_step, int* bn_layout,
+                                int precision, void* stream) {
+    SNN_REQUIRE(x && w_image && y, "snn_conv3x3_halo: null pointer");
+    SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3,
+                "snn_conv3x3_halo: precision must be SNN_PREC_FP16X3 or SNN_PREC_BF16X3 (got %d)", precision);
+    SNN_REQUIRE(halo_shape_ok(N, H, W, Cin, Cout),
+                "snn_conv3x3_halo: shape not covered (N %lld, %dx%d, %d -> %d channels; ask snn_conv3x3_halo_supported)",
+                (long long)N, H, W, Cin, Cout);
+    SNN_REQUIRE(ldx >= Cin && ldy >= Cout && ldx % 4 == 0, "snn_conv3x3_halo: bad pixel strides (%lld, %lld)",
+                (long long)ldx, (long long)ldy);
+    SNN_REQUIRE(aligned16(x) && aligned16(w_image), "snn_conv3x3_halo: x and the weight image must be 16-byte aligned");
+    SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv3x3_halo: addend pixel stride smaller than channel count");
+    SNN_REQUIRE(!addend2 || ld_addend2 >= Cout, "snn_conv3x3_halo: addend2 pixel stride smaller than channel count");
+    SNN_REQUIRE(!bn_partial || (precision == SNN_PREC_FP16X3 && bn_layout && frames_per_step > 0 && N % frames_per_step == 0 &&
+                                !addend && !addend2),
+                "snn_conv3x3_halo: statistics need the forward arithmetic, bn_layout, no addend and a frames_per_step "
+                "that divides N (%lld frames, %d per step)", (long long)N, frames_per_step);
+    SNN_REQUIRE((int64_t)4 * H * W * ldx * 4 < 0x7fffffffLL, "snn_conv3x3_halo: four images must span less than 2 GiB");
+    if (bn_layout) bn_layout[0] = bn_layout[1] = 0;
+    HaloGeom g;
+    g.ldx = ldx; g.ldy = ldy; g.ld_add = ld_addend; g.ld_add2 = ld_addend2;
+    g.N = (int)N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.PW = W + 1; g.PH = H + 1;
+    g.G = bn_partial ? frames_per_step : (int)N;
+    const int64_t group_cells = (int64_t)g.G * g.PH * g.PW;
+    g.group_cells = (int)group_cells;
+    g.tiles_per_group = (int)snn_ceil_div(group_cells, HBM_);
+    const int64_t tiles = (int64_t)(N / g.G) * g.tiles_per_group;
+    const int co_tile = Cout % 128 == 0 ? 128 : 64;
+    g.ntiles_n = Cout / co_tile;
+    SNN_REQUIRE(tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_halo: grid too large");
+    g.tiles = (int)tiles;
+    g.tiles_per_xcd = (int)snn_ceil_div(tiles, 8);
+    g.magic_pw = magic_u32(g.PW); g.magic_ph = magic_u32(g.PH);
+    g.out_vec = (ldy % 4 == 0) && aligned16(y) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
+                (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
+    g.bn_partial = bn_partial;
+    if (bn_partial) bn_layout[0] = g.tiles_per_group;   // every slot of every step is written: rows_per_chunk stays 0
+    dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
+    const unsigned char* wi = static_cast<const unsigned char*>(w_image);
+    const bool f16 = precision == SNN_PREC_FP16X3;
+#define SNN_HALO_LAUNCH(CO_, F16_)                                                                                   \
+    hipLaunchKernelGGL((k_conv_halo3<CO_, F16_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, addend2)
+    if (co_tile == 128) {
+        if (f16) SNN_HALO_LAUNCH(128, true); else SNN_HALO_LAUNCH(128, false);
+    } else {
+        if (f16) SNN_HALO_LAUNCH(64, true); else SNN_HALO_LAUNCH(64, false);
+    }
+#undef SNN_HALO_LAUNCH
+    SNN_CHECK_LAUNCH("snn_conv3x3_halo");
+    return 0;
+}
