@@ -27,7 +27,8 @@ SCRATCH = os.path.join(os.path.dirname(HERE), "build")   # tuning / stamp / cloc
 LIB_NAME = "libsnn_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 STAMP_PATH = LIB_PATH + ".buildstamp"
-SOURCES = ("elementwise.hip", "neuron.hip", "conv.hip", "wgrad_halo.hip", "detect.hip", "targets.hip")
+SOURCES = ("elementwise.hip", "neuron.hip", "conv.hip", "wgrad_halo.hip", "conv_halo.hip", "detect.hip",
+           "targets.hip")
 HEADERS = (os.path.join(CSRC, "snn_common.h"), os.path.join(INCLUDE, "snn_hip.h"))
 ARCH = "gfx950"
 # -ffp-contract=off: the pointwise kernels must round like the reference's unfused torch ops.
@@ -126,6 +127,53 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, stam
     with open(STAMP_PATH, "w") as f:
         json.dump({"sources": source_fingerprint(), "flags": FLAGS, "hipcc": cc}, f)
     return LIB_PATH
+
+
+def build_sanitized(verbose: bool = False) -> dict:
+    """HOST side of the C ABI with AddressSanitizer + UndefinedBehaviorSanitizer (``hipcc --offload-host-only``: argument
+    checks, geometry / planning / size helpers, launch set-up; no device code) -> ``build/libsnn_hip_asan.so``.
+    Sanitizers run on the CPU build only; ``tests/test_host_sanitizers.py`` drives the helpers through
+    it in a child process with the ASan runtime preloaded.  Returns the library path and the runtime to preload."""
+    hipcc = _hipcc()
+    os.makedirs(SCRATCH, exist_ok=True)
+    out = os.path.join(SCRATCH, "libsnn_hip_asan.so")
+    key = _sha(source_fingerprint().encode(), _compiler_id(hipcc).encode())
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    rt = subprocess.run([clang, "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.exists(out) and _read_stamp(out + ".buildstamp").get("key") == key):
+        cmd = [hipcc, "--offload-host-only", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+               "-fno-omit-frame-pointer", "-fPIC", "-ffp-contract=off", "-std=c++17", f"-I{INCLUDE}"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        # two steps: the host objects reference one `__hip_fatbin_<hash>` per translation unit (the device code object a
+        # full build embeds); a host-only build has none, so an EMPTY bundle stands in for each - the runtime registers
+        # it at load time and never looks inside (no kernel is ever launched from this library)
+        objs = []
+        for src in SOURCES:
+            o = os.path.join(SCRATCH, "asan_" + src.replace(".hip", ".o"))
+            c = cmd + ["-c", os.path.join(CSRC, src), "-o", o]
+            res = subprocess.run(c, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError(f"hipcc failed:\n{' '.join(c)}\n{res.stdout}\n{res.stderr}")
+            objs.append(o)
+        syms = set()
+        for o in objs:
+            for line in subprocess.run(["nm", "-u", o], capture_output=True, text=True).stdout.splitlines():
+                if "__hip_fatbin_" in line:
+                    syms.add(line.split()[-1])
+        stub = os.path.join(SCRATCH, "asan_fatbin_stub.c")
+        with open(stub, "w") as f:
+            for sym in sorted(syms):
+                f.write(f'__attribute__((aligned(4096))) const char {sym}[4096] = "__CLANG_OFFLOAD_BUNDLE__";\n')
+        res = subprocess.run([hipcc, "-fsanitize=address,undefined", "-shared", "-fPIC", "-x", "c", stub, "-x", "none",
+                              *objs, "-o", out], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link of the sanitized host library failed:\n{res.stdout}\n{res.stderr}")
+        with open(out + ".buildstamp", "w") as f:
+            json.dump({"key": key}, f)
+    return {"lib": out, "asan_runtime": rt}
 
 
 def _build_tuning(hipcc: str, verbose: bool, stamp: bool = False, clock: bool = False) -> str:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1 = 0, 1, 3, 4, 5   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY = 1, 2
 
@@ -42,6 +42,11 @@ SIGNATURES = {
                                _P]),
     "snn_weight_presplit": (c_int, [_P, _P, _L, _I, _P]),
     "snn_conv2d_fwd_bn_partial_size": (c_size_t, [_L, _I, _I, _I, _I]),
+    "snn_conv3x3_halo_supported": (c_int, [_L, _I, _I, _I, _I]),
+    "snn_conv3x3_halo_bn_chunks": (c_int64, [_I, _I, _I]),
+    "snn_weight_frag_image_bytes": (c_size_t, [_I, _I]),
+    "snn_weight_frag_image_batched": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "snn_conv3x3_halo": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P, _I, _P, _I, _P]),
     "snn_conv2d_dgrad": (c_int, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L,
                                  _I, _P]),
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,

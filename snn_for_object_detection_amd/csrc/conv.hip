@@ -2107,6 +2107,8 @@ extern "C" size_t snn_conv2d_fwd_bn_partial_size(int64_t N, int frames_per_step,
     const int64_t d = direct_bn_chunks(frames_per_step, Ho, Wo);
     if (d > chunks) chunks = d;
     if ((int64_t)frames_per_step * Ho > chunks) chunks = (int64_t)frames_per_step * Ho;   // first layer: <= one block per row
+    const int64_t hc = snn_conv3x3_halo_bn_chunks(frames_per_step, Ho, Wo);                // halo-resident 3x3 (conv_halo.hip)
+    if (hc > chunks) chunks = hc;
     return (size_t)(T * chunks * Cout * 2);
 }
 

@@ -411,7 +411,7 @@ def _slot_of(param) -> Optional[GradSlot]:
 
 
 # ------------------------------------------------------------------------------------------- conv
-def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None):
+def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_image=None):
     """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
     (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
     T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
@@ -444,8 +444,15 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None):
         prev = acc[0].result
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
-    _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), wt_split, dx.data_ptr(), Cin, T * B, H, W, Cin,
-              Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
+    if (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
+        # dx = conv3x3(dy, mirrored taps of w^T): the halo-resident kernel with the data gradient's weight image
+        if wt_image is None:
+            wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+        _hip.call("snn_conv3x3_halo", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cout, Cin,
+                  addend, ld_add, addend2, ld_add2, None, 0, None, prec, st)
+    else:
+        _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), wt_split, dx.data_ptr(), Cin, T * B, H, W, Cin,
+                  Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
     if acc is not None and (acc[0].result is None or chained):
         if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
             acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
@@ -458,6 +465,34 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None):
         o_acc.fused[o_key] = dx   # what the inner fanout will hand back for this alias
         o_acc.result = dx
     return dx
+
+
+# Halo-resident 3x3 kernel (csrc/conv_halo.hip) for the 64 / 128-channel stride-1 layers, forward and data gradient
+# (SNN_NO_HALO_CONV: tuning / bisecting aid - the implicit GEMM everywhere)
+USE_HALO_CONV = not os.environ.get("SNN_NO_HALO_CONV")
+
+
+def _halo_ok(N: int, H: int, W: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int) -> bool:
+    return (USE_HALO_CONV and KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and bool(_hip.query("snn_conv3x3_halo_supported", N, H, W, Cin, Cout)))
+
+
+def _frag_image(src: torch.Tensor, O: int, I: int, flip: int, prec: int) -> torch.Tensor:
+    """Weight image in MFMA-fragment order of ONE ``[O][3][3][I]`` matrix (snn_weight_frag_image_batched with a
+    one-row table): what a layer without a FlatTrainer-kept image builds per call (one small launch)."""
+    img = torch.empty((9 * O * I,), device=src.device, dtype=_F32)
+    table = torch.tensor([[0, 0, O, I]], dtype=torch.int64, device=src.device)
+    _hip.call("snn_weight_frag_image_batched", src.data_ptr(), img.data_ptr(), table.data_ptr(), 1,
+              9 * (I // 32) * (O // 32) * 128, flip, prec, _stream())
+    return img
+
+
+def _cached_image(weight, name: str):
+    """FlatTrainer's per-step weight image (a tensor view kept on the parameter), while the version counter matches."""
+    img = getattr(weight, name, None)
+    if img is not None and weight._snn_wt_version == weight._version:
+        return img
+    return None
 
 
 class _Conv2d(Function):
@@ -488,9 +523,17 @@ class _Conv2d(Function):
         if (fwd_prec == _hip.PREC_FP16X3 and USE_PRESPLIT_WEIGHTS and w_ohwi is w
                 and getattr(weight, "_snn_w16", None) is not None and weight._snn_wt_version == weight._version):
             w16 = weight._snn_w16.data_ptr()   # a tensor view on the parameter: alive as long as the parameter is
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), w16, y.data_ptr(), cl_stride(y),
-                  T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec,
-                  _stream())
+        halo = _halo_ok(T * B, H, W, Cin, Cout, KH, KW, stride, pad) and cl_stride(x) % 4 == 0
+        if halo and fwd_prec == _hip.PREC_FP16X3:
+            img = _cached_image(weight, "_snn_wfrag") if w_ohwi is w else None
+            if img is None:
+                img = _frag_image(w_ohwi, Cout, Cin, 0, _hip.PREC_FP16X3)
+            _hip.call("snn_conv3x3_halo", x.data_ptr(), cl_stride(x), img.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
+                      H, W, Cin, Cout, None, 0, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
+        else:
+            _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), w16, y.data_ptr(), cl_stride(y),
+                      T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec,
+                      _stream())
         if layout is not None and layout[0] > 0:
             bn_out.append(BnPartial(partial, int(layout[0]), int(layout[1]), y.data_ptr(), (T, B * Ho * Wo, Cout)))
         ctx.prec = bwd_prec
@@ -511,15 +554,16 @@ class _Conv2d(Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wref = ctx.weight_ref
-            wt16 = None
+            wt16 = wt_img = None
             if wref is not None and wref._snn_wt_version == wref._version:
                 wt = wref._snn_wt  # transposed once per optimiser step for all layers (trainer.FlatTrainer)
+                wt_img = getattr(wref, "_snn_wtfrag", None)   # ... and arranged for the halo-resident data gradient
                 if ctx.prec == _hip.PREC_BF16X3 and USE_PRESPLIT_WEIGHTS and USE_PRESPLIT_DGRAD:
                     wt16 = _ptr(getattr(wref, "_snn_wt16", None))   # ... and pre-split into its bf16 pieces
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
-            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16)
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
             if ctx.slot is not None and USE_WGRAD_STREAM:

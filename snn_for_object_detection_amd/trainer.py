@@ -74,13 +74,17 @@ class FlatTrainer:
         self.flat_wt16 = (torch.empty(total_padded, device=dev, dtype=torch.float32)
                           if dev.type == "cuda" and _HF.USE_PRESPLIT_DGRAD else None)
         self._conv_params: List[torch.nn.Parameter] = []
+        # weight images in MFMA-fragment order for the halo-resident 3x3 kernel (csrc/conv_halo.hip): forward image from
+        # the OHWI weights (fp16 pieces), data-gradient image from the transposed weights with mirrored taps (bf16)
+        self.flat_wfrag = self.flat_wtfrag = None
+        frag_table = []
         table = []
         off = 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise RuntimeError("FlatTrainer: float32 parameters only")
             # an earlier trainer's cached images must not outlive it on the parameter (they would pass the version check)
-            for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_grad_slot"):
+            for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_wfrag", "_snn_wtfrag", "_snn_grad_slot"):
                 if hasattr(p, name):
                     delattr(p, name)
             p._snn_wt_version = -1
@@ -104,9 +108,23 @@ class FlatTrainer:
                     p._snn_w16 = self.flat_w16[off:off + p.numel()]
                     if self.flat_wt16 is not None:
                         p._snn_wt16 = self.flat_wt16[off:off + p.numel()]
+                if (kh, kw) == (3, 3) and i % 32 == 0 and o % 32 == 0 and off % 4 == 0:
+                    frag_table.append((p, off, o, i))
                 self._conv_params.append(p)
             off += p.numel()
         self._wt_table = torch.tensor(table, dtype=torch.int64, device=dev) if table else None
+        self._frag_tables = None
+        if frag_table and self.flat_wt is not None:
+            self.flat_wfrag = torch.empty(total_padded, device=dev, dtype=torch.float32)
+            self.flat_wtfrag = torch.empty(total_padded, device=dev, dtype=torch.float32)
+            fwd_rows = [[f_off, 4 * f_off, o, i] for _, f_off, o, i in frag_table]
+            bwd_rows = [[f_off, 4 * f_off, i, o] for _, f_off, o, i in frag_table]   # w^T: [Cin][3][3][Cout]
+            self._frag_tables = (torch.tensor(fwd_rows, dtype=torch.int64, device=dev),
+                                 torch.tensor(bwd_rows, dtype=torch.int64, device=dev),
+                                 max(9 * (i // 32) * (o // 32) * 128 for _, _, o, i in frag_table))
+            for p, f_off, o, i in frag_table:
+                p._snn_wfrag = self.flat_wfrag[f_off:f_off + p.numel()]
+                p._snn_wtfrag = self.flat_wtfrag[f_off:f_off + p.numel()]
         self._offsets = [0]
         for p in self.params:
             self._offsets.append(self._offsets[-1] + p.numel())
@@ -177,6 +195,12 @@ class FlatTrainer:
         _hip.call("snn_weight_presplit", self.flat_param.data_ptr(), self.flat_w16.data_ptr(), n, _hip.PREC_FP16X3, st)
         if self.flat_wt16 is not None:
             _hip.call("snn_weight_presplit", self.flat_wt.data_ptr(), self.flat_wt16.data_ptr(), n, _hip.PREC_BF16X3, st)
+        if self._frag_tables is not None:
+            fwd_t, bwd_t, max_threads = self._frag_tables
+            _hip.call("snn_weight_frag_image_batched", self.flat_param.data_ptr(), self.flat_wfrag.data_ptr(),
+                      fwd_t.data_ptr(), fwd_t.shape[0], max_threads, 0, _hip.PREC_FP16X3, st)
+            _hip.call("snn_weight_frag_image_batched", self.flat_wt.data_ptr(), self.flat_wtfrag.data_ptr(),
+                      bwd_t.data_ptr(), bwd_t.shape[0], max_threads, 1, _hip.PREC_BF16X3, st)
         for p in self._conv_params:
             p._snn_wt_version = p._version
 

@@ -341,3 +341,128 @@ def test_config4_bptt_t128_gradients_match_oracle(S):
     assert rel_err(xd.grad, xr.grad) < tol, (flips, rel_err(xd.grad, xr.grad))
     for (name, pd), pr in zip(blk.named_parameters(), ref.parameters()):
         assert rel_err(pd.grad, pr.grad) < tol, (name, flips, rel_err(pd.grad, pr.grad))
+
+
+def _randomize_running_stats(model, seed):
+    """Eval-mode BatchNorm with NON-trivial running statistics (fresh buffers are mean 0 / var 1: an identity)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_((0.2 * torch.randn(m.running_mean.shape, generator=g)).to(m.running_mean.device))
+            m.running_var.copy_((0.5 + torch.rand(m.running_var.shape, generator=g)).to(m.running_var.device))
+
+
+def test_config3_1mpx_full_size_backward_is_additive_over_a_batch_split(S):
+    """The FULL-size backward pass (1280x720, 7 classes, B=8, T=32: data-gradient, weight-gradient and scan kernels
+    addressing > 2 GiB tensors) checked against something other than itself: with eval-mode BatchNorm the samples
+    decouple, so for a loss that is a SUM over samples the parameter gradient of the batch of 8 equals the gradient of
+    samples 0-3 plus the gradient of samples 4-7.  Different batch sizes mean different tile boundaries, split-K
+    partitions and pixel offsets for the same samples - a wrong (but repeatable) address past 2 GiB cannot pass.
+    Sums are ordered and fp32: agreement to 2e-5 per parameter tensor."""
+    import gc
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 32, 8, 720, 1280
+    X = synthetic_events(T, B, H, W, p=0.02).cuda()
+    A = 170280
+    g = torch.Generator().manual_seed(11)
+    P_cls = torch.randn(B, A, 8, generator=g).cuda() / A
+    P_box = torch.randn(B, A, 4, generator=g).cuda() / A
+
+    def grads(sl):
+        torch.manual_seed(2)
+        model = S.TinyYolo(num_classes=7, time_window=0).cuda()
+        _randomize_running_stats(model, 3)
+        model.eval()
+        tr = FlatTrainer(model)
+        tr.zero_grad()
+        _, cls, box = model(X[:, sl])
+        loss = (cls * P_cls[sl]).sum() + (box * P_box[sl]).sum()
+        loss.backward()
+        tr.synchronize()
+        out = tr.flat_grad.clone()
+        offsets, names = list(tr._offsets), [n for n, p in model.named_parameters() if p.requires_grad]
+        del model, tr, loss, cls, box
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out, offsets, names
+
+    g_all, offsets, names = grads(slice(0, 8))
+    g_lo, _, _ = grads(slice(0, 4))
+    g_hi, _, _ = grads(slice(4, 8))
+    g_sum = g_lo + g_hi
+    assert torch.isfinite(g_all).all() and g_all.abs().max() > 0
+    assert not torch.equal(g_lo, g_hi)
+    worst = ("", 0.0)
+    for k, name in enumerate(names):
+        a, b = g_all[offsets[k]:offsets[k + 1]], g_sum[offsets[k]:offsets[k + 1]]
+        if b.norm() > 0:
+            e = rel_err(a, b)
+            if e > worst[1]:
+                worst = (name, e)
+    assert worst[1] < 2e-5, worst
+    del X, g_all, g_lo, g_hi, g_sum
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _deep12(S):
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm
+    layers = []
+    for _ in range(12):
+        layers += [Conv(64, 3), Norm(), LIF()]
+    torch.manual_seed(5)
+    blk = BlockGen(2, layers)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return blk.cuda()
+
+
+def test_config4_deep12_real_per_gpu_share_b2_t128(S):
+    """BASELINE configs[4] at the size one GPU really gets (240x304, B=2 of the 16, T=128, ~170 GiB): (1) the backward
+    scan in four 32-step segments (functional.SCAN_SEGMENT_T) equals the one-launch scan at that size (the per-(t, c)
+    BatchNorm sums are added over another block partition and the parameter gradients over another segment order, so
+    "equal" is to fp32 summation order: 1e-5 on the whole gradient; the small-size test checks gx bit for bit);
+    (2) with eval-mode BatchNorm the gradient of the batch of 2 is the sum of the two single-sample gradients
+    (sum-over-samples read-out) - the size-triggered paths (long pixel ranges of the weight gradient, > 2 GiB pixel
+    splits, segmented scans) against an independent decomposition of the same work."""
+    import gc
+    from snn_for_object_detection_amd import functional as HF
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 128, 2, 240, 304
+    X = synthetic_events(T, B, H, W, p=0.3, seed=4).cuda()
+    probe = torch.randn(B, 64, H, W, generator=torch.Generator().manual_seed(3)).cuda() / (H * W)
+
+    def grads(sl, train, segment):
+        blk = _deep12(S)
+        _randomize_running_stats(blk, 7)
+        blk.train(train)
+        tr = FlatTrainer(blk)
+        tr.zero_grad()
+        old = HF.SCAN_SEGMENT_T
+        HF.SCAN_SEGMENT_T = segment
+        try:
+            out, _ = blk(X[:, sl], last_only=True)
+            (out * probe[sl]).sum().backward()
+            tr.synchronize()
+        finally:
+            HF.SCAN_SEGMENT_T = old
+        g = tr.flat_grad.clone()
+        del blk, tr, out
+        gc.collect()
+        torch.cuda.empty_cache()
+        return g
+
+    # (1) train mode (the bench's mode): segmented == one launch
+    g_seg = grads(slice(0, 2), True, 32)
+    g_one = grads(slice(0, 2), True, None)
+    assert torch.isfinite(g_seg).all() and g_seg.abs().max() > 0
+    assert rel_err(g_seg, g_one) < 1e-5
+    del g_seg, g_one
+    # (2) eval mode: additive over the batch split
+    g_all = grads(slice(0, 2), False, 32)
+    g_sum = grads(slice(0, 1), False, 32) + grads(slice(1, 2), False, 32)
+    assert g_all.abs().max() > 0 and rel_err(g_all, g_sum) < 2e-5
+    del X, g_all, g_sum
+    gc.collect()
+    torch.cuda.empty_cache()

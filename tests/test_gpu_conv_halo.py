@@ -1,0 +1,218 @@
+"""Halo-resident 3x3 convolution (csrc/conv_halo.hip, ``snn_conv3x3_halo``) through the C ABI: forward and data
+gradient against torch's CPU convolution in fp64 (the op the reference instantiates, models/modules/layer_gen.py:129-136),
+channel-sliced operands, fused addends, BatchNorm statistics partials, determinism, and the padded-strip edge cases
+(images narrower than a tile, one-pixel images, the widest supported row, tiles that end inside a group)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H_(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from snn_for_object_detection_amd import _hip
+    return _hip
+
+
+def _image(_hip, src, O, I, flip, prec):
+    img = torch.empty(9 * O * I, device="cuda")
+    table = torch.tensor([[0, 0, O, I]], dtype=torch.int64, device="cuda")
+    _hip.call("snn_weight_frag_image_batched", src.data_ptr(), img.data_ptr(), table.data_ptr(), 1,
+              9 * (I // 32) * (O // 32) * 128, flip, prec, torch.cuda.current_stream().cuda_stream)
+    return img
+
+
+HALO_CASES = [
+    # N, H, W, Cin, Cout
+    (6, 30, 38, 128, 128),    # the neck-1 bottleneck shape: 128-wide tile, four chunks
+    (3, 60, 76, 64, 64),      # backbone stage 2: 64-wide tile, two chunks
+    (7, 15, 19, 128, 128),    # neck-2 maps
+    (9, 8, 10, 128, 128),     # neck-3 maps: a tile spans more than one image
+    (5, 7, 5, 32, 64),        # one chunk, rows far shorter than a tile (several images per tile)
+    (3, 1, 1, 64, 64),        # one-pixel images: every tap but the centre reads a pad cell
+    (2, 9, 78, 64, 128),      # the widest supported row (PW = 79)
+    (2, 33, 41, 96, 192),     # three chunks, three 64-wide channel tiles
+    (1, 5, 6, 32, 256),       # two 128-wide channel tiles
+    (4, 12, 70, 64, 128),     # tiles ending inside an image row
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", HALO_CASES)
+def test_halo_forward_and_data_gradient_against_fp64(H_, N, H, W, Cin, Cout):
+    _hip = H_
+    assert _hip.query("snn_conv3x3_halo_supported", N, H, W, Cin, Cout) == 1
+    torch.manual_seed(N * 100 + H + W + Cin)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(N, H, W, Cin)
+    w = torch.randn(Cout, 3, 3, Cin) / (9 * Cin) ** 0.5              # OHWI
+    gy = torch.randn(N, H, W, Cout)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_()
+    yr = F.conv2d(xr, w.permute(0, 3, 1, 2).double(), padding=1)
+    yr.backward(gy.permute(0, 3, 1, 2).double())
+    y_ref, dx_ref = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+
+    xd, wd, gyd = x.cuda(), w.cuda(), gy.cuda()
+    # forward: fp16 x 3 image of the OHWI weights
+    img = _image(_hip, wd, Cout, Cin, 0, _hip.PREC_FP16X3)
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    _hip.call("snn_conv3x3_halo", xd.data_ptr(), Cin, img.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Cout, None, 0, None,
+              0, None, 0, None, _hip.PREC_FP16X3, st)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, y_ref) < 2e-6
+    # the implicit-GEMM kernel computes the same products (other summation order)
+    y_g = torch.empty_like(y)
+    _hip.call("snn_conv2d_fwd", xd.data_ptr(), Cin, wd.data_ptr(), None, y_g.data_ptr(), Cout, N, H, W, Cin, H, W, Cout, 3, 3,
+              1, 1, None, 0, None, 0, None, _hip.PREC_FP16X3, st)
+    assert rel_err(y, y_g) < 2e-6
+    # data gradient: bf16 x 3 image of the transposed weights with mirrored taps; "Cin" of the call = the layer's Cout
+    wt = torch.empty(Cin, 3, 3, Cout, device="cuda")
+    _hip.call("snn_weight_transpose", wd.data_ptr(), wt.data_ptr(), Cout, 3, 3, Cin, st)
+    if _hip.query("snn_conv3x3_halo_supported", N, H, W, Cout, Cin) == 1:
+        img_t = _image(_hip, wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        _hip.call("snn_conv3x3_halo", gyd.data_ptr(), Cout, img_t.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cout, Cin, None, 0,
+                  None, 0, None, 0, None, _hip.PREC_BF16X3, st)
+        assert torch.isfinite(dx).all()
+        assert rel_err(dx, dx_ref) < 3e-5                           # bf16 x 3: 16-bit products
+        # bitwise reproducible
+        dx2 = torch.empty_like(dx)
+        _hip.call("snn_conv3x3_halo", gyd.data_ptr(), Cout, img_t.data_ptr(), dx2.data_ptr(), Cin, N, H, W, Cout, Cin, None,
+                  0, None, 0, None, 0, None, _hip.PREC_BF16X3, st)
+        assert torch.equal(dx, dx2)
+
+
+def test_halo_channel_slices_and_fused_addends(H_):
+    """Operands that are channel slices of wider channels-last buffers (pixel stride > channel count: the zero-copy Dense
+    merge) and the two fused addends of the data-gradient epilogue; untouched neighbours of the output slice."""
+    _hip = H_
+    torch.manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    N, H, W, Cin, Cout = 4, 15, 19, 64, 128
+    xbuf = torch.randn(N, H, W, Cin + 32, device="cuda")             # x = channels 16 .. 16+Cin of a wider buffer
+    x = xbuf[..., 16:16 + Cin]
+    ybuf = torch.full((N, H, W, Cout + 64), 7.0, device="cuda")      # y = channels 32 .. 32+Cout
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda") / (9 * Cin) ** 0.5
+    a1 = torch.randn(N, H, W, Cout + 8, device="cuda")               # addends with their own pixel strides
+    a2 = torch.randn(N, H, W, Cout, device="cuda")
+    img = _image(_hip, w, Cout, Cin, 0, _hip.PREC_FP16X3)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + a1[..., 4:4 + Cout].double().cpu() + a2.double().cpu()
+    _hip.call("snn_conv3x3_halo", x.data_ptr(), Cin + 32, img.data_ptr(), ybuf[..., 32:].data_ptr(), Cout + 64, N, H, W, Cin,
+              Cout, a1[..., 4:].data_ptr(), Cout + 8, a2.data_ptr(), Cout, None, 0, None, _hip.PREC_FP16X3, st)
+    assert rel_err(ybuf[..., 32:32 + Cout], ref) < 2e-6
+    assert bool((ybuf[..., :32] == 7.0).all()) and bool((ybuf[..., 32 + Cout:] == 7.0).all())
+    # an output slice that is not 16-byte aligned takes the scalar store path
+    ybuf2 = torch.full((N, H, W, Cout + 3), 7.0, device="cuda")
+    _hip.call("snn_conv3x3_halo", x.data_ptr(), Cin + 32, img.data_ptr(), ybuf2[..., 1:].data_ptr(), Cout + 3, N, H, W, Cin,
+              Cout, None, 0, a2.data_ptr(), Cout, None, 0, None, _hip.PREC_FP16X3, st)
+    assert rel_err(ybuf2[..., 1:1 + Cout], ref - a1[..., 4:4 + Cout].double().cpu()) < 2e-6
+    assert bool((ybuf2[..., 0] == 7.0).all()) and bool((ybuf2[..., 1 + Cout:] == 7.0).all())
+
+
+@pytest.mark.parametrize("T,B,H,W,Cin,Cout", [(3, 2, 30, 38, 64, 64), (4, 3, 15, 19, 128, 128), (5, 1, 8, 10, 64, 128),
+                                             (2, 5, 60, 76, 64, 64), (6, 2, 3, 4, 32, 64)])
+def test_halo_batchnorm_statistics_partials(H_, T, B, H, W, Cin, Cout):
+    """The partials the forward leaves for the BatchNorm behind it (per timestep, tiles never straddle two steps) give
+    the sums of the stored values - against fp64 sums of y and against the separate statistics pass."""
+    _hip = H_
+    torch.manual_seed(T + B + H)
+    st = torch.cuda.current_stream().cuda_stream
+    N, M = T * B, B * H * W
+    x = torch.randn(N, H, W, Cin, device="cuda") + 0.5
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda") / (9 * Cin) ** 0.5
+    img = _image(_hip, w, Cout, Cin, 0, _hip.PREC_FP16X3)
+    y = torch.empty(N, H, W, Cout, device="cuda")
+    n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", N, B, H, W, Cout)
+    partial = torch.full((n_part,), float("nan"), device="cuda", dtype=torch.float64)
+    layout = (ctypes.c_int * 2)()
+    _hip.call("snn_conv3x3_halo", x.data_ptr(), Cin, img.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Cout, None, 0, None, 0,
+              partial.data_ptr(), B, layout, _hip.PREC_FP16X3, st)
+    assert layout[0] == _hip.query("snn_conv3x3_halo_bn_chunks", B, H, W) and layout[1] == 0
+    assert T * layout[0] * Cout * 2 <= n_part
+    yref = torch.empty_like(y)
+    _hip.call("snn_conv3x3_halo", x.data_ptr(), Cin, img.data_ptr(), yref.data_ptr(), Cout, N, H, W, Cin, Cout, None, 0, None,
+              0, None, 0, None, _hip.PREC_FP16X3, st)
+    assert torch.equal(y, yref)                                        # statistics do not change the values
+    sums = torch.empty(T, Cout, 2, device="cuda", dtype=torch.float64)
+    _hip.call("snn_bn_stats_reduce", partial.data_ptr(), layout[0], layout[1], T, M, Cout, sums.data_ptr(), st)
+    y64 = y.double().view(T, M, Cout)
+    exact = torch.stack([y64.sum(1), (y64 * y64).sum(1)], dim=-1)
+    assert torch.isfinite(sums).all() and rel_err(sums, exact) < 1e-13
+    # and through the finalize kernel: mean / invstd equal to the separate pass's
+    gamma, bias = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+
+    def finalize(part, chunks, rpc):
+        out = [torch.empty(T, Cout, device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        _hip.call("snn_bn_stats_finalize", part.data_ptr(), chunks, rpc, T, M, Cout, gamma.data_ptr(), bias.data_ptr(), 1e-5,
+                  0.1, rm.data_ptr(), rv.data_ptr(), 0, *[o.data_ptr() for o in out], st)
+        return out + [rm, rv]
+
+    part2 = torch.empty(_hip.query("snn_bn_stats_partial_size", T, M, Cout), device="cuda", dtype=torch.float64)
+    _hip.call("snn_bn_stats", y.data_ptr(), Cout, T, M, Cout, part2.data_ptr(), st)
+    for g_, w_ in zip(finalize(partial, layout[0], layout[1]), finalize(part2, 0, 0)):
+        assert torch.isfinite(g_).all() and rel_err(g_, w_) < 2e-7
+
+
+def test_halo_refuses_uncovered_shapes(H_):
+    _hip = H_
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 4, 100, 64, device="cuda")
+    img = torch.zeros(9 * 64 * 64, device="cuda")
+    y = torch.zeros(1, 4, 100, 64, device="cuda")
+    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 64) == 0          # row longer than the halo window
+    with pytest.raises(RuntimeError, match="shape not covered"):
+        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 100, 64, 64, None, 0, None, 0,
+                  None, 0, None, _hip.PREC_FP16X3, st)
+    with pytest.raises(RuntimeError, match="precision"):
+        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 50, 64, 64, None, 0, None, 0,
+                  None, 0, None, _hip.PREC_FP32, st)
+
+
+def test_halo_kernel_serves_the_model_layers_and_matches_the_implicit_gemm(H_):
+    """Module level: the same BlockGen with the halo-resident kernel on and off (functional.USE_HALO_CONV) - outputs,
+    input gradient and weight gradients agree to the split-product tolerances; with a FlatTrainer the per-step weight
+    images give the same bits as images built per call."""
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm
+    from snn_for_object_detection_amd import functional as HF
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    torch.manual_seed(11)
+    T, B, H, W = 3, 2, 15, 19
+    cfg = lambda: [Conv(64, 3), Norm(), LIF(), Conv(128, 3), Norm(), LIF(), Conv(128, 3)]  # noqa: E731
+    blk = BlockGen(32, cfg()).cuda().train()
+    x = (torch.rand(T, B, 32, H, W, device="cuda") < 0.3).float()
+    res = {}
+    for on in (True, False):
+        HF.USE_HALO_CONV = on
+        try:
+            for m in blk.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            xin = x.clone().requires_grad_()
+            out, _ = blk(xin)
+            blk.zero_grad(set_to_none=True)
+            out.square().mean().backward()
+            res[on] = (out.detach().clone(), xin.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+        finally:
+            HF.USE_HALO_CONV = True
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    assert rel_err(res[True][1], res[False][1]) < 1e-4
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel_err(a, b) < 1e-4
+    # trainer-kept images == per-call images (bit for bit)
+    tr = FlatTrainer(blk, lr=1e-3)
+    conv_w = [p for p in blk.parameters() if p.dim() == 4 and p.shape[1] >= 64][0]
+    assert isinstance(conv_w._snn_wfrag, torch.Tensor) and isinstance(conv_w._snn_wtfrag, torch.Tensor)
+    tr.zero_grad()
+    xin = x.clone().requires_grad_()
+    out_t, _ = blk(xin)
+    out_t.square().mean().backward()
+    tr.synchronize()
+    assert torch.equal(xin.grad, res[True][1])

@@ -75,6 +75,13 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert n >= 32 * (5 * 120 * 152 // 128 + 1) * 64 * 2           # >= the implicit-GEMM layout (128-row tiles)
     assert n >= 32 * 5 * 15 * 10 * 64 * 2                           # >= the 8x16-patch layout of the direct kernel
     assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 7, 120, 152, 64) == 0   # frames per step must divide N
+    # ... and the halo-resident 3x3 kernel's layout (strip tiles of 128 cells per timestep), where that kernel applies
+    assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 128) == 1
+    assert hip_lib.snn_conv3x3_halo_supported(160, 120, 152, 64, 64) == 0      # strip row longer than its halo window
+    assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 32) == 0       # <= 32 output channels: direct kernel
+    assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) == (5 * 31 * 39 + 127) // 128
+    assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 5, 30, 38, 128) >= 32 * hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) * 128 * 2
+    assert hip_lib.snn_weight_frag_image_bytes(128, 64) == 9 * 128 * 64 * 4
 
 
 def test_ctypes_signatures_agree_with_the_header():
@@ -84,7 +91,7 @@ def test_ctypes_signatures_agree_with_the_header():
     from snn_for_object_detection_amd import _hip
     header = open(os.path.join(os.path.dirname(_hip._HERE), "include", "snn_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
-    protos = re.findall(r"\b(int|size_t|const char\s*\*)\s+(snn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    protos = re.findall(r"\b(int64_t|int|size_t|const char\s*\*)\s+(snn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
     assert len(protos) == len(_hip.SIGNATURES), (len(protos), len(_hip.SIGNATURES))
 
     def ctype_of(decl):
@@ -96,7 +103,7 @@ def test_ctypes_signatures_agree_with_the_header():
 
     for ret, name, params in protos:
         restype, argtypes = _hip.SIGNATURES[name]
-        want_ret = {"int": c_int, "size_t": c_size_t}.get(ret, c_char_p)
+        want_ret = {"int": c_int, "size_t": c_size_t, "int64_t": c_int64}.get(ret, c_char_p)
         assert restype is want_ret, (name, restype, want_ret)
         decls = [] if params.strip() in ("", "void") else params.split(",")
         assert len(decls) == len(argtypes), (name, len(decls), len(argtypes))

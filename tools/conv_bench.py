@@ -16,6 +16,8 @@ from snn_for_object_detection_amd import _hip  # noqa: E402
 
 SHAPES = [  # Cin, Cout, k, s, H, W (input size), label
     (128, 128, 3, 1, 30, 38, "c3(128) x4"),
+    (128, 128, 3, 1, 15, 19, "c3(128) neck2 x3"),
+    (128, 128, 3, 1, 8, 10, "c3(128) neck3 x2"),
     (64, 64, 3, 1, 60, 76, "c3(64) x3"),
     (32, 32, 3, 1, 120, 152, "c3(32) x2"),
     (64, 128, 3, 2, 120, 152, "down 64->128"),
@@ -64,8 +66,20 @@ def main():
             "wgrad": lambda: _hip.call("snn_conv2d_wgrad", x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), N,
                                        H, W, Cin, Ho, Wo, Cout, k, k, s, pad, 0, ws.data_ptr(), splitk, 1, st),
         }
+        if k == 3 and s == 1 and _hip.query("snn_conv3x3_halo_supported", N, H, W, Cin, Cout):
+            def image(src, O, I, flip, prec):
+                img = torch.empty(9 * O * I, device=dev)
+                table = torch.tensor([[0, 0, O, I]], dtype=torch.int64, device=dev)
+                _hip.call("snn_weight_frag_image_batched", src.data_ptr(), img.data_ptr(), table.data_ptr(), 1,
+                          9 * (I // 32) * (O // 32) * 128, flip, prec, st)
+                return img
+            img_f, img_b = image(w, Cout, Cin, 0, 4), image(wt, Cin, Cout, 1, 1)
+            ops["fwd_halo"] = lambda: _hip.call("snn_conv3x3_halo", x.data_ptr(), Cin, img_f.data_ptr(), y.data_ptr(), Cout, N,
+                                                H, W, Cin, Cout, None, 0, None, 0, None, 0, None, 4, st)
+            ops["dgrad_halo"] = lambda: _hip.call("snn_conv3x3_halo", dy.data_ptr(), Cout, img_b.data_ptr(), dx.data_ptr(), Cin,
+                                                  N, H, W, Cout, Cin, None, 0, None, 0, None, 0, None, 1, st)
         for name, fn in ops.items():
-            if args.only and name != args.only:
+            if args.only and not name.startswith(args.only):
                 continue
             for _ in range(2):
                 fn()
