@@ -141,6 +141,19 @@ int snn_weight_presplit(const float* w, void* out, int64_t n, int precision, voi
  *   valid for SNN_PREC_FP16X3 (fwd) / SNN_PREC_BF16X3 (dgrad) only.  With it the kernels stop converting the weight
  *   tile in every block; the results are bit-identical to the conversion on the fly.  Shapes whose kernel cannot use
  *   it read `w` / `wt` as before, so both pointers are always passed. */
+/* Weight gradient with the BatchNorm-backward affine applied while dy is READ (no materialised dy): the gradient that
+ * reaches the convolution through a train-mode BatchNorm (layer_gen.py:211-214) is dy = A[t][c]*gx + B[t][c]*y + C[t][c]
+ * (snn_bn_bwd_apply); when nothing else consumes dy - the event-frame layer, whose input needs no gradient - the
+ * weight-gradient kernel forms it on the fly from gx (the scan's output, pixel stride ldgx), the saved convolution
+ * output y (ldy) and coef = [3][T][Cout] (A, B, C planes), t = frame / frames_per_step.  Same statement, same
+ * roundings as snn_bn_bwd_apply + snn_conv2d_wgrad.  snn_conv2d_wgrad_bn_supported: 1 for the shapes covered (the
+ * event-frame row kernel: Cin = 2, 3x3); workspace / splitk as for snn_conv2d_wgrad. */
+int snn_conv2d_wgrad_bn_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                  int pad);
+int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ldgx, const float* y, int64_t ldy,
+                        const float* coef, int T, int frames_per_step, float* dw, int64_t N, int H, int W, int Cin, int Ho,
+                        int Wo, int Cout, int KH, int KW, int stride, int pad, int accumulate, float* workspace, int splitk,
+                        void* stream);
 /* ---- Halo-resident 3x3 / stride 1 / pad 1 convolution (csrc/conv_halo.hip): forward AND data gradient of the 64- and
  * 128-channel layers (reference models/modules/layer_gen.py:129-136, nn.Conv2d(C, C', 3, padding=1, bias=False)).
  * The activation halo of a tile is fetched and split into its 16-bit pieces once per 32-channel chunk (the implicit

@@ -42,6 +42,9 @@ SIGNATURES = {
                                _P]),
     "snn_weight_presplit": (c_int, [_P, _P, _L, _I, _P]),
     "snn_conv2d_fwd_bn_partial_size": (c_size_t, [_L, _I, _I, _I, _I]),
+    "snn_conv2d_wgrad_bn_supported": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "snn_conv2d_wgrad_bn": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                    _P, _I, _P]),
     "snn_conv3x3_halo_supported": (c_int, [_L, _I, _I, _I, _I]),
     "snn_conv3x3_halo_bn_chunks": (c_int64, [_I, _I, _I]),
     "snn_weight_frag_image_bytes": (c_size_t, [_I, _I]),

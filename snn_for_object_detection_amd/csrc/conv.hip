@@ -1877,11 +1877,18 @@ struct FirstGeom {
     // BatchNorm partials: then a group is a TIMESTEP and block j of it writes chunk j of partial[t][c][chunk][2].
     int group_rows, group_blocks;
     double* bn_partial;
+    // weight gradient with the BatchNorm-backward affine applied on the fly (BNAPPLY): the `dy` operand is gx and
+    // dy = A[t][c] * gx + B[t][c] * y + C[t][c], t = image / frames_per_step; coef = [3][T][C]
+    const float* bn_y;
+    int64_t bn_ldy;
+    const float* bn_coef;
+    int bn_tc;   // T * C: distance between the three coefficient planes
+    int bn_fps;  // frames per timestep
 };
 
 // One block walks output ROWS (block-uniform row index: the image / row split and the vertical bounds are scalar
 // work), its PP pixel lanes walk the row; per pixel all nine input positions are loaded before any is tested.
-template <int CIN, int KS, bool WGRAD>
+template <int CIN, int KS, bool WGRAD, bool BNAPPLY = false>
 __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          FirstGeom g) {
@@ -1934,6 +1941,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
         __syncthreads();
         const float* dyrow = WGRAD ? dy + (int64_t)r * g.Wo * g.ldy + cg * 4 : nullptr;
         float* yrow = WGRAD ? nullptr : out + (int64_t)r * g.Wo * g.ldy + cg * 4;
+        const float* byrow = nullptr;
+        f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca, cc = ca;
+        if constexpr (WGRAD && BNAPPLY) {   // the row's timestep is block-uniform: three coefficient quads per row
+            byrow = g.bn_y + (int64_t)r * g.Wo * g.bn_ldy + cg * 4;
+            const float* cf = g.bn_coef + (int64_t)(img / g.bn_fps) * g.Cout + cg * 4;
+            ca = *reinterpret_cast<const f32x4*>(cf);
+            cb = *reinterpret_cast<const f32x4*>(cf + g.bn_tc);
+            cc = *reinterpret_cast<const f32x4*>(cf + 2 * (int64_t)g.bn_tc);
+        }
         float row_s[4] = {0.f, 0.f, 0.f, 0.f}, row_q[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ox = pl; ox < g.Wo; ox += PP) {
             float2 taps[KS][KS];
@@ -1943,6 +1959,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
                 for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow[kh * LW + ox * g.stride + kw];
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
             if (WGRAD) gv = *reinterpret_cast<const f32x4*>(dyrow + ox * ldy);
+            if constexpr (WGRAD && BNAPPLY) {   // the statement of k_bn_bwd_apply (neuron.hip): same roundings
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(byrow + ox * (int)g.bn_ldy);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gv[c] = ca[c] * gv[c] + cb[c] * yv[c] + cc[c];
+            }
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kh = 0; kh < KS; ++kh)
@@ -2148,7 +2169,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
     if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 && aligned16(y) &&
         (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
-        FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), 0, nullptr};
+        FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), 0, nullptr,
+                        nullptr, 0, nullptr, 0, 1};
         int blocks = fg.rows < 8 * snn_num_cu() ? fg.rows : 8 * snn_num_cu();
         fg.group_blocks = blocks;
         if (bn_partial) {
@@ -2348,6 +2370,43 @@ static int wgrad_reduce_slabs(float* workspace, float* dw, int64_t n, int splitk
     return 0;
 }
 
+namespace {
+static bool first_layer_wgrad_ok(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t N, int H, int W, int Cin,
+                                 int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad) {
+    return first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
+           (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
+           (Wo - 1) * stride + 3 <= W + 2 * pad;
+}
+}  // namespace
+
+extern "C" int snn_conv2d_wgrad_bn_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                             int stride, int pad) {
+    // the event-frame layer's row kernel (pointer alignment is checked by the call itself)
+    return (N > 0 && first_layer_shape(Cin, Cout, KH, KW) && N * (int64_t)Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
+            (Wo - 1) * stride + 3 <= W + 2 * pad) ? 1 : 0;
+}
+
+extern "C" int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ldgx, const float* y, int64_t ldy,
+                                   const float* coef, int T, int frames_per_step, float* dw, int64_t N, int H, int W,
+                                   int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                   float* workspace, int splitk, void* stream) {
+    SNN_REQUIRE(x && gx && y && coef && dw && workspace, "snn_conv2d_wgrad_bn: null pointer");
+    if (check_conv_shape("snn_conv2d_wgrad_bn", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
+    SNN_REQUIRE(frames_per_step > 0 && T > 0 && (int64_t)T * frames_per_step == N,
+                "snn_conv2d_wgrad_bn: %lld frames are not %d timesteps of %d", (long long)N, T, frames_per_step);
+    SNN_REQUIRE(ldx >= Cin && ldgx >= Cout && ldy >= Cout, "snn_conv2d_wgrad_bn: pixel stride smaller than channel count");
+    SNN_REQUIRE(splitk >= 1 && splitk <= 32768, "snn_conv2d_wgrad_bn: bad splitk %d", splitk);
+    SNN_REQUIRE(first_layer_wgrad_ok(x, ldx, gx, ldgx, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad) && ldy % 4 == 0 &&
+                    aligned16(y) && aligned16(coef) && (int64_t)Wo * ldy < 0x7fffffffLL && (int64_t)Wo * ldgx < 0x7fffffffLL,
+                "snn_conv2d_wgrad_bn: shape / alignment not covered (ask snn_conv2d_wgrad_bn_supported)");
+    FirstGeom fg = {ldx, ldgx, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
+                    y, ldy, coef, T * Cout, frames_per_step};
+    hipLaunchKernelGGL((k_conv_first<2, 3, true, true>), dim3((unsigned)splitk), dim3(kThreads),
+                       (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, gx, workspace, fg);
+    SNN_CHECK_LAUNCH("snn_conv2d_wgrad_bn");
+    return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * KH * KW * Cin, splitk, accumulate, (hipStream_t)stream);
+}
+
 extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                                 int accumulate, float* workspace, int splitk, int precision, void* stream) {
@@ -2365,10 +2424,9 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
-    if (first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
-        (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
-        (Wo - 1) * stride + 3 <= W + 2 * pad) {
-        FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr};
+    if (first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) {
+        FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
+                        nullptr, 0, nullptr, 0, 1};
         hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
                            (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");

@@ -27,6 +27,7 @@
 //   * one barrier per k-step of 24 MFMAs per wave; the only VALU in the loop is the fragment address arithmetic.
 // Epilogue as in k_conv_gather: accumulators transposed through LDS, 16-byte stores, up to two fused addends
 // (gradient accumulation), BatchNorm statistics partials of the stored values (forward).
+#include <stdlib.h>
 #include "snn_common.h"
 
 namespace {
@@ -93,7 +94,9 @@ __device__ __forceinline__ int cell_slot_off(int cell, int slot) { return cell *
 
 // CO: output channels per block (64 | 128); F16: fp16 pieces (forward) or bf16 pieces (data gradient).
 // 4 waves as 2 x 2: a wave owns 64 cells x CO/2 channels (TM = 2 row tiles, TN = CO/64 column tiles of 32 x 32).
-template <int CO, bool F16>
+// ABL (tuning builds only, timing experiments with WRONG results): 1 no weight DMA, 2 no per-k-step wait + barrier,
+// 4 no halo prefetch loads, 8 no output stores, 16 no fragment reads of the halo image (one read per k-step instead)
+template <int CO, bool F16, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
                                                            const unsigned char* __restrict__ wimg,
                                                            float* __restrict__ y, HaloGeom g,
@@ -203,6 +206,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int off = cell_slot_off(cellbase[i] + tapoff, 2 * ks + h);
+                if constexpr (ABL & 16) {
+                    if (i == 0 && ks == 0) ah[0] = *reinterpret_cast<const bf16x8*>(Aimg + off);
+                    ah[i] = ah[0];
+                    al[i] = ah[0];
+                    continue;
+                }
                 ah[i] = *reinterpret_cast<const bf16x8*>(Aimg + off);
                 al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
             }
@@ -249,19 +258,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             const int kk = chunk * 9 + tap;
             const int cur = kk & 1;
             // the other buffer was read during the previous k-step (every wave has passed that step's barrier)
-            if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
+            if constexpr (!(ABL & 1))
+                if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             // one staging pass of the next chunk's halo per tap: it is YOUNGER than this step's LDS-DMA, so the
             // counted wait below leaves it in flight for a whole k-step (out-of-range offsets when there is no next chunk)
-            pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            if constexpr (!(ABL & 4))
+                pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
             kstep((kh - 1) * g.PW + (kw - 1), Bimg + cur * BTILE);
             // this wave's share of the next weight tile has landed (all but the youngest vector-memory operation are
             // done); the barrier makes every wave's share visible and retires this step's reads of the current buffer
             // (lgkmcnt(0): this wave's fragment reads have really left the LDS before another wave may overwrite them)
-            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ABL & 2) asm volatile("" ::: "memory");
+            else if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (more) {   // every wave is past its last read of this chunk's halo image: swap in the next one
             store_halo();
@@ -302,6 +315,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             const bool ok = m < cells_left && xx < g.W && yy < g.H && n < g.N && nch < g.Cout;
             f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
             if (!ok) continue;
+            if constexpr (ABL & 8) {
+                asm volatile("" :: "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]));
+                continue;
+            }
             const int64_t pix = ((int64_t)n * g.H + yy) * g.W + xx;
             float* dst = y + pix * g.ldy + nch;
             if (ovec) {
@@ -507,6 +524,19 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     const bool f16 = precision == SNN_PREC_FP16X3;
 #define SNN_HALO_LAUNCH(CO_, F16_)                                                                                   \
     hipLaunchKernelGGL((k_conv_halo3<CO_, F16_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, addend2)
+#ifdef SNN_TUNING
+    if (const char* e = snn_tuning_env("SNN_HALO_ABL")) {   // timing experiments (tools/halo_abl.py): WRONG results
+        const int abl = atoi(e);
+#define SNN_HALO_ABL_LAUNCH(A_) \
+        if (abl == A_) { \
+            if (co_tile == 128) hipLaunchKernelGGL((k_conv_halo3<128, true, A_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, addend2); \
+            else hipLaunchKernelGGL((k_conv_halo3<64, true, A_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, addend2); \
+            SNN_CHECK_LAUNCH("snn_conv3x3_halo"); return 0; }
+        SNN_HALO_ABL_LAUNCH(1) SNN_HALO_ABL_LAUNCH(2) SNN_HALO_ABL_LAUNCH(4) SNN_HALO_ABL_LAUNCH(8) SNN_HALO_ABL_LAUNCH(16)
+        SNN_HALO_ABL_LAUNCH(3) SNN_HALO_ABL_LAUNCH(7) SNN_HALO_ABL_LAUNCH(15) SNN_HALO_ABL_LAUNCH(31)
+#undef SNN_HALO_ABL_LAUNCH
+    }
+#endif
     if (co_tile == 128) {
         if (f16) SNN_HALO_LAUNCH(128, true); else SNN_HALO_LAUNCH(128, false);
     } else {

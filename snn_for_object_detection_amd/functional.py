@@ -495,6 +495,43 @@ def _cached_image(weight, name: str):
     return None
 
 
+class PendingBnApply(NamedTuple):
+    """Second phase of a train-mode BatchNorm backward that has NOT been run: dy = A[t,c]*gx + B[t,c]*y + C[t,c]
+    (snn_bn_bwd_apply).  ``_AffineNeuron.backward`` hands its producer convolution gx together with this record when that
+    convolution announced (``y._snn_defer_apply``) that its backward forms dy while reading it (snn_conv2d_wgrad_bn):
+    the 12-bytes-per-element apply pass and the dy tensor disappear."""
+    gx: torch.Tensor      # dense [T,B,H,W,C]
+    y: torch.Tensor       # the convolution output saved for the BatchNorm backward ([T,B,C,H,W], channels-last)
+    coef: torch.Tensor    # [3, T, C]
+    dims: Tuple[int, int, int, int, int]   # T, B, C, H, W
+
+
+_PENDING_APPLY = {}   # gx.data_ptr() -> PendingBnApply
+USE_DEFERRED_BN_APPLY = not os.environ.get("SNN_NO_DEFERRED_BN_APPLY")   # tuning / bisecting aid
+
+
+def reset_backward_state() -> None:
+    """Drop records of a backward pass that did not finish (an exception between the two nodes)."""
+    _PENDING_APPLY.clear()
+
+
+def _apply_pending(pend: PendingBnApply) -> None:
+    """The classic second phase, in place: gx becomes dy."""
+    T, B, C, H, W = pend.dims
+    _hip.call("snn_bn_bwd_apply", pend.gx.data_ptr(), pend.y.data_ptr(), cl_stride(pend.y), pend.coef[0].data_ptr(),
+              pend.coef[1].data_ptr(), pend.coef[2].data_ptr(), pend.gx.data_ptr(), C, T, B * H * W, C, 0, _stream())
+
+
+def _wgrad_bn_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, pad: int) -> bool:
+    """The convolution's weight gradient can apply the BatchNorm-backward affine itself and nothing else needs dy."""
+    if not (USE_DEFERRED_BN_APPLY and weight.requires_grad and not x.requires_grad and x.dim() == 5):
+        return False
+    T, B, Cin, H, W = x.shape
+    Cout, _, KH, KW = weight.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    return bool(_hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
+
+
 class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
@@ -552,6 +589,28 @@ class _Conv2d(Function):
         ldg, ldx = cl_stride(gy), cl_stride(x)
         st = _stream()
         dx = dw = None
+        pend = _PENDING_APPLY.pop(gy.data_ptr(), None)
+        if pend is not None:
+            fused = (not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.slot is not None
+                     and pend.dims == (T, B, Cout, Ho, Wo) and cl_stride(pend.y) % 4 == 0
+                     and _hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
+            if fused:
+                # dy is formed while the weight-gradient kernel reads gx and y: no apply pass, no dy tensor
+                splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
+                main = torch.cuda.current_stream()
+                stream = _side_stream(x.device) if USE_WGRAD_STREAM else main
+                if USE_WGRAD_STREAM:
+                    _side_retire(main, WGRAD_SIDE_DEPTH)
+                    stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
+                    _hip.call("snn_conv2d_wgrad_bn", x.data_ptr(), ldx, pend.gx.data_ptr(), Cout, pend.y.data_ptr(),
+                              cl_stride(pend.y), pend.coef.data_ptr(), T, B, ctx.slot.buf.data_ptr(), T * B, H, W, Cin, Ho,
+                              Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, stream.cuda_stream)
+                if USE_WGRAD_STREAM:
+                    _side_hold(stream, x, pend.gx, pend.y, pend.coef)
+                return None, None, None, None, None, None, None, None, None
+            _apply_pending(pend)   # this convolution takes a materialised dy after all
         if ctx.needs_input_grad[0]:
             wref = ctx.weight_ref
             wt16 = wt_img = None
@@ -718,6 +777,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
     y = y[0] if single else y
     if bn_out:
         y._snn_bn_partial = bn_out[0]
+    if bn_stats and not single and _slot_of(weight) is not None and _wgrad_bn_ok(seq, weight, int(stride), int(padding)):
+        y._snn_defer_apply = True   # (bn_stats: the BatchNorm behind is y's only consumer)
     return y
 
 
@@ -770,7 +831,7 @@ class _AffineNeuron(Function):
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
-         sync_group, bn_hint, last_only) = cfg
+         sync_group, bn_hint, last_only, defer_apply) = cfg
         _require_device(y, "norm/neuron input")
         ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
@@ -866,6 +927,7 @@ class _AffineNeuron(Function):
                       _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params,
                       _hip.SCAN_LAST_STEP_ONLY if last_only else 0, st)
         ctx.ckpt = ckpt
+        ctx.defer_apply = defer_apply
         ctx.last_only = last_only
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
         ctx.slots = (g_slot, b_slot)
@@ -1005,7 +1067,10 @@ class _AffineNeuron(Function):
                 _hip.call("snn_bn_bwd_coef", raw.data_ptr(), raw_local.data_ptr(), param_sums.data_ptr(), T, M * world,
                           C, _ptr(gamma), mean.data_ptr(), invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                           coef[2].data_ptr(), dg_ptr, db_ptr, acc_flag, st)
-            if need_y and not use_running:
+            if need_y and not use_running and ctx.defer_apply and ctx.sync_group is None:
+                # the producing convolution forms dy itself while it reads gx (see PendingBnApply)
+                _PENDING_APPLY[gx.data_ptr()] = PendingBnApply(gx, y, coef, (T, B, C, H, W))
+            elif need_y and not use_running:
                 # in place: dy overwrites gx
                 _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), ldy, coef[0].data_ptr(),
                           coef[1].data_ptr(), coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
@@ -1034,6 +1099,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     Returns ``(out, NeuronState | None)``.
     """
     bn_hint = getattr(y, "_snn_bn_partial", None)
+    defer_apply = bool(getattr(y, "_snn_defer_apply", False))
     seq, single = as_sequence(y)
     if addend is not None:
         acc = _acc_of(addend)
@@ -1065,7 +1131,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
             v0, i0 = state
     sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
-           dest, sync_group, bn_hint, bool(last_only) and not single)
+           dest, sync_group, bn_hint, bool(last_only) and not single, defer_apply)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, addend, cfg)
     if neuron == _hip.NEURON_NONE:
         new_state = None

@@ -211,6 +211,7 @@ class FlatTrainer:
         if self._early_work is not None:   # a backward pass whose step() never came: let its collective finish first
             self._early_work.wait()
             self._early_work = None
+        _HF.reset_backward_state()
         self.flat_grad.zero_()
         for p, slot in zip(self.params, self.slots):
             slot.written = False

@@ -336,3 +336,45 @@ def test_skipped_parameters_keep_their_own_step_count_like_torch(S):
         stepper.step()
     for (n, pb), pc in zip(mb.named_parameters(), mc.parameters()):
         assert rel_err(pc, pb) < 1e-5, n
+
+
+def test_event_frame_layer_forms_dy_inside_its_weight_gradient(S):
+    """The BatchNorm behind the event-frame convolution hands its producer gx instead of dy (functional.PendingBnApply):
+    ``snn_conv2d_wgrad_bn`` applies dy = A*gx + B*y + C while reading - the apply pass and the dy tensor are gone.  Same
+    statement, same roundings: the flat gradient is BIT-identical to the two-kernel path, and without grad slots (plain
+    autograd) the classic path still runs."""
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm, _hip
+    from snn_for_object_detection_amd import functional as HF
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 5, 3, 34, 46
+    x = synthetic_events(T, B, H, W, p=0.1).cuda()
+    calls = []
+    real_call = _hip.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+
+    res = {}
+    for fused in (True, False):
+        HF.USE_DEFERRED_BN_APPLY = fused
+        try:
+            torch.manual_seed(4)
+            blk = BlockGen(2, [Conv(64, 3, 2), Norm(), LIF(), Conv(16, 1), Norm(), LIF()]).cuda().train()
+            tr = FlatTrainer(blk, lr=1e-3)
+            tr.zero_grad()
+            calls.clear()
+            _hip.call = spy
+            try:
+                out, _ = blk(x)
+                (out * torch.linspace(0.5, 1.5, out.numel(), device="cuda").view(out.shape)).mean().backward()
+            finally:
+                _hip.call = real_call
+            tr.synchronize()
+            res[fused] = (tr.flat_grad.clone(), list(calls))
+            assert not HF._PENDING_APPLY                       # every record was consumed
+        finally:
+            HF.USE_DEFERRED_BN_APPLY = True
+    assert res[True][1].count("snn_conv2d_wgrad_bn") == 1 and res[False][1].count("snn_conv2d_wgrad_bn") == 0
+    assert res[True][1].count("snn_bn_bwd_apply") == res[False][1].count("snn_bn_bwd_apply") - 1
+    assert res[True][0].abs().max() > 0 and torch.equal(res[True][0], res[False][0])
