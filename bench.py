@@ -55,7 +55,8 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3 / fp16x3) or 6 (bf16x6)
     dense 16-bit MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
     backward = (kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
-                or kernel.endswith(", true>"))  # k_conv_direct3<BN, WM, WN, DGRAD>
+                or kernel.endswith(", true>")     # k_conv_direct3<BN, WM, WN, DGRAD>
+                or "dgrad" in kernel)             # k_conv_halo3<CO, dgrad>, k_conv_s2dgrad3
     prec = bwd_prec if backward else fwd_prec
     if prec == "bf16":
         return PEAK_BF16_MATRIX_TFLOPS, "bf16 dense MFMA, one product"
@@ -110,10 +111,12 @@ def pmc_traffic(config: str, kernel: str):
     (tools/pmc_traffic.py; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  bench.py cannot run the profiler
     on itself, so the number comes from profiles/ - and only while that file was measured on the CURRENT kernel
     sources; otherwise the field is null and the provenance says why."""
-    name = f"r02_pmc_traffic_{config}.json"
-    path = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{config}.json")))   # newest round last
+    if not cands:
         return None, {"file": None, "note": "no PMC traffic file for this workload under profiles/"}
+    path = cands[-1]
+    name = os.path.basename(path)
     data = json.load(open(path))
     meta = data.get("_meta", {})
     now = csrc_fingerprint()
@@ -123,6 +126,22 @@ def pmc_traffic(config: str, kernel: str):
         src["note"] = "stale: kernel sources changed since the PMC passes; traffic nulled"
         return None, src
     return data.get(kernel, {}).get("hbm_bytes_per_launch"), src
+
+
+def dominant_template(prof):
+    """The single kernel TEMPLATE (entry point + shape class) with the most time inside the profiled steps, beside the
+    family the roofline is quoted for: {"kernel", "ms_per_step", "tflops", "gbs", "launches_per_step"}."""
+    agg = {}
+    for label, flops, byts, start, end in prof.records:
+        row = agg.setdefault(label, [0.0, 0.0, 0.0, 0])
+        row[0] += start.elapsed_time(end)
+        row[1] += flops
+        row[2] += byts
+        row[3] += 1
+    label, (ms, flops, byts, calls) = max(agg.items(), key=lambda kv: kv[1][0])
+    sec = max(ms, 1e-9) * 1e-3
+    return {"kernel": label, "ms_per_step": ms / 2, "tflops": flops / sec / 1e12, "gbs": byts / sec / 1e9,
+            "launches_per_step": calls // 2}
 
 
 def cpu_baseline(config, H, W, num_classes, threads, p):
@@ -380,7 +399,8 @@ def main():
         roofline = {
             **head, "traffic": traffic, "traffic_source": traffic_src,
             "achieved_tflops": row["tflops"], "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
-            "avg_launch_us": row["avg_us"], "launches_per_step": row["calls"] // 2,
+            "dominant_template": dominant_template(prof), "avg_launch_us": row["avg_us"],
+            "launches_per_step": row["calls"] // 2,
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],
             "all_kernels_ms_per_step": total_ms / 2,

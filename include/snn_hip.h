@@ -170,6 +170,15 @@ int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ld
  *       channels (for a data gradient: x = dy, "Cin" = the layer's Cout and vice versa).  precision = the image's.
  *       bn_partial / frames_per_step / bn_layout as for snn_conv2d_fwd (forward arithmetic only, no addend); the partials
  *       hold snn_conv2d_fwd_bn_partial_size() doubles, bn_layout[0] = snn_conv3x3_halo_bn_chunks(), bn_layout[1] = 0. */
+/* Data gradient of a 3x3 / stride 2 / pad 1 convolution in ONE pass over dy (csrc/conv_halo.hip, k_conv_s2dgrad3): the
+ * four stride-phase classes of dx are produced from one staged dy halo instead of four launches that each gather dy
+ * again.  wt_image = the layer's data-gradient image (snn_weight_frag_image_batched of the transposed weights, flip = 1,
+ * SNN_PREC_BF16X3 - the image the stride-1 data gradient uses).  dx[N][H][W][lddx] (Cin channels) from dy[N][Ho][Wo][lddy]
+ * (Cout channels), Ho = (H-1)/2 + 1; addend / addend2 as for snn_conv2d_dgrad.  bf16 x 3 arithmetic. */
+int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout);
+int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W,
+                         int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
+                         int64_t ld_addend2, void* stream);
 int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int Cout);
 int64_t snn_conv3x3_halo_bn_chunks(int frames_per_step, int H, int W);
 size_t snn_weight_frag_image_bytes(int O, int I);

@@ -61,6 +61,7 @@ struct HaloGeom {
     unsigned magic_pw, magic_ph;   // ceil(2^32 / d): q = umulhi(n, magic) for n * d < 2^32 (small n only)
     int out_vec;
     double* bn_partial;         // forward statistics partials [t][c][chunk][2] (null: none); chunk = tile of the group
+    int OH, OW;                 // k_conv_s2dgrad3 only: size of the produced tensor dx (the strip grid H x W is dy's)
 };
 
 __device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -384,6 +385,205 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     }
 }
 
+// ---- data gradient of the 3x3 / stride 2 / pad 1 convolutions in ONE pass over dy.
+//     dx[n, hi, wi, ci] = sum_{kh,kw} dy[n, (hi+1-kh)/2, (wi+1-kw)/2, co] * w[co, kh, kw, ci]     (exact divisions only)
+// The implicit GEMM runs one launch per stride-phase class (hi % 2, wi % 2): four launches that each gather dy again
+// (PMC, profiles/r02: 1.4x the algorithmic bytes) with K loops of only 1, 2, 2 and 4 taps - prologue and epilogue
+// dominate (64 -> 128 at 120x152: 643 us against 383 us for the forward of the same layer).  Here a block owns 128
+// consecutive cells of dy's padded strip (rows of PW = Wo + 1 cells, see k_conv_halo3) and produces ALL FOUR classes
+// of the 2x2 dx pixels under them: per 32-channel chunk the dy halo (the tile plus PW + 1 cells BEHIND it - the taps
+// reach down / right only) is staged once, and the nine taps are nine k-steps that each add into the accumulator set of
+// their class: kh = 1 -> even rows from dy row a; kh = 0 -> odd rows from dy row a + 1; kh = 2 -> odd rows from dy row a
+// (columns alike).  Four accumulator sets of 32 cells x 64 channels per wave (128 registers), 4 waves over the cells,
+// 64 dx channels per block.  The weight image is the stride-1 data-gradient image (mirrored taps): tap t is read at 8 - t.
+template <bool UNUSED = false>
+__global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __restrict__ x,   // dy
+                                                              const unsigned char* __restrict__ wimg,
+                                                              float* __restrict__ y,         // dx
+                                                              HaloGeom g, const float* __restrict__ addend,
+                                                              const float* __restrict__ addend2) {
+    constexpr int CO = 64, TN = 2;
+    constexpr int BTILE = (CO / 32) * 4096;
+    constexpr int NDMA = (CO / 32) * 4 / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE];
+    unsigned char* Aimg = smem;
+    unsigned char* Bimg = smem + 2 * HPIECE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row tile of the wave (4 x 32 cells)
+    const int r = lane & 31, h = lane >> 5;
+
+    const int bq = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) * g.tiles_per_xcd + bq / g.ntiles_n;
+    if (tile >= g.tiles) return;
+    const int n0c = (bq % g.ntiles_n) * CO;
+    const int c0 = tile * HBM_;                                  // one group: all N images
+    const int R0g = c0 / g.PW, x0 = c0 - R0g * g.PW;
+    const int n0 = R0g / g.PH, y0 = R0g - n0 * g.PH;
+    const int nb = n0;                                           // the halo reaches forward only
+
+    const int quad = tid & 7;
+    const int64_t ipix = (int64_t)g.H * g.W;
+    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * 4;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (int64_t)nb * ipix * g.ldx), 0, xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+    unsigned voff[NPASS];
+    int awr[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int cell = p * 32 + (tid >> 3);                    // halo cell = strip cell (tile start) + cell
+        const unsigned u = (unsigned)(x0 + cell);
+        const unsigned dR = udiv_small(u, g.magic_pw);
+        const int xx = (int)(u - dR * g.PW);
+        const unsigned v = (unsigned)(y0 + (int)dR);
+        const unsigned dn = udiv_small(v, g.magic_ph);
+        const int yy = (int)(v - dn * g.PH);
+        const int n = n0 + (int)dn;
+        const bool ok = n < g.N && xx < g.W && yy < g.H;
+        const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
+        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;
+        awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
+    }
+    const int cellbase = wave * 32 + r;
+    const int nchunks = g.Cin >> 5;
+    const int co_tiles = g.Cout >> 5;
+    const unsigned char* wsrc = wimg + (int64_t)(n0c >> 5) * 4096 + lane * 16;
+    const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bimg;
+    auto dma_b = [&](int kk, int buf) {   // kk = chunk * 9 + tap; the image holds mirrored taps
+        const int chunk = kk / 9, tap = kk - chunk * 9;
+        const unsigned char* src = wsrc + ((int64_t)((8 - tap) * nchunks + chunk) * co_tiles) * 4096 + wave * 1024;
+        const unsigned dst = lds_b + buf * BTILE + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + q * 4096), "s"(__builtin_amdgcn_readfirstlane(dst + q * 4096))
+                         : "memory");
+        }
+    };
+    f32x4 pf[NPASS];
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            u32x2 hi, lo;
+            split4<false>(pf[p], hi, lo);
+            *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
+            *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+        }
+    };
+    f32x16 acc[4][TN];   // [class = 2 * (hi % 2) + (wi % 2)]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
+
+    auto kstep = [&](int tapoff, const unsigned char* Bb, f32x16 (&a)[TN]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = cell_slot_off(cellbase + tapoff, 2 * ks + h);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Aimg + off);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int boff = j * 4096 + ks * 2048 + lane * 16;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bb + boff);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bb + boff + 1024);
+                a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a[j], 0, 0, 0);
+                a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a[j], 0, 0, 0);
+                a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a[j], 0, 0, 0);
+            }
+        }
+    };
+
+    dma_b(0, 0);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+        pf[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[p], 0, 0));
+    store_halo();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int nk = nchunks * 9;
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        const int cbytes = (chunk + 1) * 128;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kk = chunk * 9 + tap;
+            const int cur = kk & 1;
+            if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int dummy = 0; (void)dummy;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            // kh = 1: even dx rows, dy row a; kh = 0: odd rows, dy row a + 1; kh = 2: odd rows, dy row a (columns alike)
+            const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
+            const int dh = kh == 0 ? 1 : 0, dw = kw == 0 ? 1 : 0;
+            kstep(dh * g.PW + dw, Bimg + cur * BTILE, acc[2 * ph + pw]);
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (more) {
+            store_halo();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- epilogue: per class, the wave's 32 cells x 64 channels through LDS to 16-byte stores at dx pixel (2a+ph, 2b+pw)
+    constexpr int EW = TN * 32 + 4, LPR = TN * 8, RPP = 64 / LPR;
+    float* stage = reinterpret_cast<float*>(smem) + wave * 32 * EW;
+    const bool ovec = g.out_vec != 0;
+    const int lrow = lane / LPR, c4 = (lane % LPR) * 4;
+    const int nch = n0c + c4;
+    const int cells_left = g.group_cells - c0;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * h) * EW + j * 32 + r] = acc[cls][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+            const int row = pass * RPP + lrow;
+            const int m = wave * 32 + row;
+            const unsigned u = (unsigned)(x0 + m);
+            const unsigned dR = udiv_small(u, g.magic_pw);
+            const int bb = (int)(u - dR * g.PW);
+            const unsigned v = (unsigned)(y0 + (int)dR);
+            const unsigned dn = udiv_small(v, g.magic_ph);
+            const int aa = (int)(v - dn * g.PH);
+            const int n = n0 + (int)dn;
+            const int hi = 2 * aa + ph, wi = 2 * bb + pw;
+            const bool ok = m < cells_left && bb < g.W && aa < g.H && hi < g.OH && wi < g.OW && n < g.N && nch < g.Cout;
+            f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
+            if (!ok) continue;
+            const int64_t pix = ((int64_t)n * g.OH + hi) * g.OW + wi;
+            float* dst = y + pix * g.ldy + nch;
+            if (ovec) {
+                if (addend) val += *reinterpret_cast<const f32x4*>(addend + pix * g.ld_add + nch);
+                if (addend2) val += *reinterpret_cast<const f32x4*>(addend2 + pix * g.ld_add2 + nch);
+                *reinterpret_cast<f32x4*>(dst) = val;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float o = val[q];
+                    if (addend) o += addend[pix * g.ld_add + nch + q];
+                    if (addend2) o += addend2[pix * g.ld_add2 + nch + q];
+                    dst[q] = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // ---- weight image in MFMA-fragment order.  src: [O][3][3][I] fp32 (the forward's OHWI weights, or the transposed
 // [Cin][KH][KW][Cout] matrix for the data gradient with flip = 1: tap t of the image is tap 8 - t of src).
 // image: [tap][I/32][O/32][k16 (2)][piece (2)][lane (64)] x 16 bytes; lane (r, h) holds src[o = 32*ot + r][tap][i = 32*ic +
@@ -447,7 +647,60 @@ static bool halo_shape_ok(int64_t N, int H, int W, int Cin, int Cout) {
     return true;
 }
 
+
+static bool s2dgrad_shape_ok(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout) {
+    // Cin: the layer's input channels (dx), Cout: its output channels (dy, the K dimension)
+    if (N <= 0 || H <= 0 || W <= 0) return false;
+    if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return false;     // 3x3, stride 2, pad 1
+    if (Cout % 32 != 0 || Cout < 32 || Cin % 64 != 0) return false;
+    if (128 + (Wo + 1) + 2 > HCELLS) return false;                        // the tile and the PW + 1 cells behind it
+    if (N * (int64_t)(Ho + 1) * (Wo + 1) >= 0x7fffffffLL) return false;
+    return true;
+}
 }  // namespace
+
+extern "C" int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout) {
+    return s2dgrad_shape_ok(N, H, W, Cin, Ho, Wo, Cout) ? 1 : 0;
+}
+
+extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N,
+                                    int H, int W, int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend,
+                                    const float* addend2, int64_t ld_addend2, void* stream) {
+    SNN_REQUIRE(dy && wt_image && dx, "snn_conv3x3_s2_dgrad: null pointer");
+    SNN_REQUIRE(s2dgrad_shape_ok(N, H, W, Cin, Ho, Wo, Cout),
+                "snn_conv3x3_s2_dgrad: shape not covered (N %lld, %dx%d -> %dx%d, %d -> %d channels; ask "
+                "snn_conv3x3_s2_dgrad_supported)", (long long)N, H, W, Ho, Wo, Cin, Cout);
+    SNN_REQUIRE(lddy >= Cout && lddx >= Cin && lddy % 4 == 0, "snn_conv3x3_s2_dgrad: bad pixel strides (%lld, %lld)",
+                (long long)lddy, (long long)lddx);
+    SNN_REQUIRE(aligned16(dy) && aligned16(wt_image), "snn_conv3x3_s2_dgrad: dy and the weight image must be 16-byte aligned");
+    SNN_REQUIRE(!addend || ld_addend >= Cin, "snn_conv3x3_s2_dgrad: addend pixel stride smaller than channel count");
+    SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv3x3_s2_dgrad: addend2 pixel stride smaller than channel count");
+    SNN_REQUIRE((int64_t)4 * Ho * Wo * lddy * 4 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: four dy images must span less than 2 GiB");
+    HaloGeom g;
+    g.ldx = lddy; g.ldy = lddx; g.ld_add = ld_addend; g.ld_add2 = ld_addend2;
+    g.N = (int)N; g.H = Ho; g.W = Wo;          // the strip grid is dy's
+    g.Cin = Cout;                              // K: dy channels
+    g.Cout = Cin;                              // produced channels: dx
+    g.OH = H; g.OW = W;
+    g.PW = Wo + 1; g.PH = Ho + 1;
+    g.G = (int)N;
+    const int64_t cells = N * (int64_t)g.PH * g.PW;
+    g.group_cells = (int)cells;
+    g.tiles_per_group = (int)snn_ceil_div(cells, HBM_);
+    g.tiles = g.tiles_per_group;
+    g.ntiles_n = Cin / 64;
+    SNN_REQUIRE((int64_t)g.tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: grid too large");
+    g.tiles_per_xcd = (int)snn_ceil_div(g.tiles, 8);
+    g.magic_pw = magic_u32(g.PW); g.magic_ph = magic_u32(g.PH);
+    g.out_vec = (lddx % 4 == 0) && aligned16(dx) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
+                (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
+    g.bn_partial = nullptr;
+    dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
+    hipLaunchKernelGGL((k_conv_s2dgrad3<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
+                       static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
+    SNN_CHECK_LAUNCH("snn_conv3x3_s2_dgrad");
+    return 0;
+}
 
 extern "C" int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int Cout) {
     return halo_shape_ok(N, H, W, Cin, Cout) ? 1 : 0;
@@ -518,6 +771,7 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     g.out_vec = (ldy % 4 == 0) && aligned16(y) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = bn_partial;
+    g.OH = H; g.OW = W;
     if (bn_partial) bn_layout[0] = g.tiles_per_group;   // every slot of every step is written: rows_per_chunk stays 0
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     const unsigned char* wi = static_cast<const unsigned char*>(w_image);

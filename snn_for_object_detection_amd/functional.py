@@ -444,7 +444,14 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
         prev = acc[0].result
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
-    if (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
+    if (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
+            and _hip.query("snn_conv3x3_s2_dgrad_supported", T * B, H, W, Cin, Ho, Wo, Cout)):
+        # stride 2: all four phase classes of dx from ONE staged pass over dy (k_conv_s2dgrad3)
+        if wt_image is None:
+            wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+        _hip.call("snn_conv3x3_s2_dgrad", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin, Ho,
+                  Wo, Cout, addend, ld_add, addend2, ld_add2, st)
+    elif (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
         # dx = conv3x3(dy, mirrored taps of w^T): the halo-resident kernel with the data gradient's weight image
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)

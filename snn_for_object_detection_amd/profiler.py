@@ -53,6 +53,21 @@ def work_of(name: str, a):
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
         byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
         return _conv_label(name, a), flops, byts
+    if name == "snn_conv3x3_halo":   # halo-resident 3x3 / stride 1 (csrc/conv_halo.hip): forward (fp16 x 3) or data gradient
+        n, h, w, cin, cout, prec = a[5], a[6], a[7], a[8], a[9], a[17]
+        flops = 2.0 * n * h * w * cout * 9 * cin
+        byts = 4.0 * (n * h * w * cin + n * h * w * cout + cout * 9 * cin)
+        return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, {'fwd' if prec == 4 else 'dgrad'}>", flops, byts
+    if name == "snn_conv3x3_s2_dgrad":   # one-pass stride-2 data gradient
+        n, h, w, cin, ho, wo, cout = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        flops = 2.0 * n * ho * wo * cout * 9 * cin
+        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * 9 * cin)
+        return "k_conv_s2dgrad3<dgrad>", flops, byts
+    if name == "snn_conv2d_wgrad_bn":   # event-frame weight gradient with the BatchNorm-backward affine applied on the fly
+        n, h, w, cin, ho, wo, cout, kh, kw = a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18]
+        flops = 2.0 * n * ho * wo * cout * kh * kw * cin
+        byts = 4.0 * (n * h * w * cin + 2 * n * ho * wo * cout + cout * kh * kw * cin)   # x, gx and y are read
+        return "k_conv_wgrad", flops, byts
     if name == "snn_affine_neuron_fwd":
         neuron, T, M, C = a[0], a[14], a[15], a[16]
         last_only = bool(a[18] & 2)   # SNN_SCAN_LAST_STEP_ONLY: the output of ONE step is written

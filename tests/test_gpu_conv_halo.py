@@ -216,3 +216,50 @@ def test_halo_kernel_serves_the_model_layers_and_matches_the_implicit_gemm(H_):
     out_t.square().mean().backward()
     tr.synchronize()
     assert torch.equal(xin.grad, res[True][1])
+
+
+S2_CASES = [
+    # N, H, W, Cin (dx channels), Cout (dy channels)
+    (4, 120, 152, 64, 128),   # backbone 64 -> 128 (the slowest data gradient of the step)
+    (3, 60, 76, 128, 256),    # neck-1 entry
+    (5, 30, 38, 256, 256),    # neck-2 entry
+    (6, 15, 19, 256, 256),    # neck-3 entry: odd input size (15 -> 8, 19 -> 10)
+    (3, 9, 11, 64, 32),       # odd sizes, one K chunk
+    (2, 1, 1, 64, 64),        # one-pixel images
+    (2, 2, 2, 64, 64),        # even size 2: dx pixels (1, .) only reach dy row 0 through kh = 2
+    (1, 17, 310, 64, 64),     # the widest supported dy row (Wo = 155, PW = 156)
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", S2_CASES)
+def test_one_pass_stride2_data_gradient_against_fp64(H_, N, H, W, Cin, Cout):
+    _hip = H_
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert _hip.query("snn_conv3x3_s2_dgrad_supported", N, H, W, Cin, Ho, Wo, Cout) == 1
+    torch.manual_seed(N + H + W)
+    st = torch.cuda.current_stream().cuda_stream
+    w = torch.randn(Cout, 3, 3, Cin) / (9 * Cin) ** 0.5
+    gy = torch.randn(N, Ho, Wo, Cout)
+    xr = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w.permute(0, 3, 1, 2).double(), stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    dx_ref = xr.grad.permute(0, 2, 3, 1)
+    wd, gyd = w.cuda(), gy.cuda()
+    wt = torch.empty(Cin, 3, 3, Cout, device="cuda")
+    _hip.call("snn_weight_transpose", wd.data_ptr(), wt.data_ptr(), Cout, 3, 3, Cin, st)
+    img_t = _image(_hip, wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+    a1 = torch.randn(N, H, W, Cin, device="cuda")
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    _hip.call("snn_conv3x3_s2_dgrad", gyd.data_ptr(), Cout, img_t.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
+              None, 0, None, 0, st)
+    assert torch.isfinite(dx).all()                                   # every dx pixel of every class was written
+    assert rel_err(dx, dx_ref) < 3e-5
+    # the four-launch implicit GEMM computes the same products
+    dx_g = torch.empty_like(dx)
+    _hip.call("snn_conv2d_dgrad", gyd.data_ptr(), Cout, wt.data_ptr(), None, dx_g.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
+              3, 3, 2, 1, None, 0, None, 0, _hip.PREC_BF16X3, st)
+    assert rel_err(dx, dx_g) < 3e-6
+    # fused addend, determinism
+    dx2 = torch.empty_like(dx)
+    _hip.call("snn_conv3x3_s2_dgrad", gyd.data_ptr(), Cout, img_t.data_ptr(), dx2.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
+              a1.data_ptr(), Cin, None, 0, st)
+    assert torch.equal(dx2, dx + a1)

@@ -74,5 +74,55 @@ def main():
             print(f"{name:13s} min {min(t):7.1f} us  median {statistics.median(t):7.1f} us  {flops / statistics.median(t) / 1e6:6.1f} TF")
 
 
+def stride2():
+    """The one-pass stride-2 data gradient against the four-launch implicit GEMM (and the forward of the same layer)."""
+    _hip.load()
+    dev = torch.device("cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for N, H, W, Cin, Cout in [(160, 120, 152, 64, 128), (160, 60, 76, 128, 256), (160, 30, 38, 256, 256), (160, 15, 19, 256, 256)]:
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        x = torch.randn(N, H, W, Cin, device=dev)
+        dy = torch.randn(N, Ho, Wo, Cout, device=dev)
+        w = torch.randn(Cout, 3, 3, Cin, device=dev) * 0.05
+        wt = torch.empty(Cin, 3, 3, Cout, device=dev)
+        y, dx = torch.empty(N, Ho, Wo, Cout, device=dev), torch.empty(N, H, W, Cin, device=dev)
+        _hip.call("snn_weight_transpose", w.data_ptr(), wt.data_ptr(), Cout, 3, 3, Cin, st)
+        img = torch.empty(9 * Cout * Cin, device=dev)
+        table = torch.tensor([[0, 0, Cin, Cout]], dtype=torch.int64, device=dev)
+        _hip.call("snn_weight_frag_image_batched", wt.data_ptr(), img.data_ptr(), table.data_ptr(), 1,
+                  9 * (Cout // 32) * (Cin // 32) * 128, 1, 1, st)
+        ops = {
+            "fwd gather": lambda: _hip.call("snn_conv2d_fwd", x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, H, W,
+                                            Cin, Ho, Wo, Cout, 3, 3, 2, 1, None, 0, None, 0, None, 4, st),
+            "dgrad 4-pass": lambda: _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), None, dx.data_ptr(), Cin, N,
+                                              H, W, Cin, Ho, Wo, Cout, 3, 3, 2, 1, None, 0, None, 0, 1, st),
+            "dgrad 1-pass": lambda: _hip.call("snn_conv3x3_s2_dgrad", dy.data_ptr(), Cout, img.data_ptr(), dx.data_ptr(), Cin, N,
+                                              H, W, Cin, Ho, Wo, Cout, None, 0, None, 0, st),
+        }
+        t0 = time.time()
+        while time.time() - t0 < 1.0:
+            for fn in ops.values():
+                fn()
+            torch.cuda.synchronize()
+        times = {k: [] for k in ops}
+        for _ in range(10):
+            for name, fn in ops.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times[name].append(1e3 * e0.elapsed_time(e1) / 10)
+        flops = 2.0 * N * Ho * Wo * Cout * 9 * Cin
+        print(f"--- stride 2: N{N} {H}x{W} {Cin}->{Cout}")
+        for name, t in times.items():
+            print(f"{name:13s} min {min(t):7.1f} us  median {statistics.median(t):7.1f} us  {flops / statistics.median(t) / 1e6:6.1f} TF")
+
+
 if __name__ == "__main__":
-    main()
+    if "--stride2" in sys.argv:
+        sys.argv.remove("--stride2")
+        stride2()
+    else:
+        main()
