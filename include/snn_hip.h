@@ -179,6 +179,17 @@ int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, int Ho, int
 int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W,
                          int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
                          int64_t ld_addend2, void* stream);
+/* Data gradient of a 3x3 / stride 1 / pad 1 convolution behind a train-mode BatchNorm with the BatchNorm-backward affine
+ * applied while gx is staged (k_conv_halo3<BNAP>): dy = A[t][c]*gx + B[t][c]*y + C[t][c] (see snn_conv2d_wgrad_bn; coef =
+ * [3][T][Cin], T = N / frames_per_step) is formed once per staged cell, written to dy_out (dense [N][H][W][Cin], for the
+ * weight gradient) by the tile that owns the cell, and convolved with the data-gradient image into dx[N][H][W][lddx]
+ * (Cout channels) (+ addends).  gx and y are dense [N][H][W][Cin].  Here Cin = channels of gx / y / dy (the layer's
+ * OUTPUT channels), Cout = channels of dx (the layer's input channels).  bf16 x 3 arithmetic, same statement and
+ * roundings for dy as snn_bn_bwd_apply. */
+int snn_conv3x3_halo_bn_supported(int64_t N, int H, int W, int Cin, int Cout, int frames_per_step);
+int snn_conv3x3_halo_bn(const float* gx, const float* y, const float* coef, int frames_per_step, float* dy_out,
+                        const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W, int Cin, int Cout,
+                        const float* addend, int64_t ld_addend, const float* addend2, int64_t ld_addend2, void* stream);
 int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int Cout);
 int64_t snn_conv3x3_halo_bn_chunks(int frames_per_step, int H, int W);
 size_t snn_weight_frag_image_bytes(int O, int I);

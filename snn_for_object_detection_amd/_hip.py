@@ -47,6 +47,8 @@ SIGNATURES = {
                                     _P, _I, _P]),
     "snn_conv3x3_s2_dgrad_supported": (c_int, [_L, _I, _I, _I, _I, _I, _I]),
     "snn_conv3x3_s2_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
+    "snn_conv3x3_halo_bn_supported": (c_int, [_L, _I, _I, _I, _I, _I]),
+    "snn_conv3x3_halo_bn": (c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     "snn_conv3x3_halo_supported": (c_int, [_L, _I, _I, _I, _I]),
     "snn_conv3x3_halo_bn_chunks": (c_int64, [_I, _I, _I]),
     "snn_weight_frag_image_bytes": (c_size_t, [_I, _I]),

@@ -62,6 +62,7 @@ struct HaloGeom {
     int out_vec;
     double* bn_partial;         // forward statistics partials [t][c][chunk][2] (null: none); chunk = tile of the group
     int OH, OW;                 // k_conv_s2dgrad3 only: size of the produced tensor dx (the strip grid H x W is dy's)
+    int bn_T, bn_tc, bn_fps;    // BNAP: timesteps, T * Cin (distance of the coefficient planes), frames per timestep
 };
 
 __device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -97,18 +98,31 @@ __device__ __forceinline__ int cell_slot_off(int cell, int slot) { return cell *
 // 4 waves as 2 x 2: a wave owns 64 cells x CO/2 channels (TM = 2 row tiles, TN = CO/64 column tiles of 32 x 32).
 // ABL (tuning builds only, timing experiments with WRONG results): 1 no weight DMA, 2 no per-k-step wait + barrier,
 // 4 no halo prefetch loads, 8 no output stores, 16 no fragment reads of the halo image (one read per k-step instead)
-template <int CO, bool F16, int ABL = 0>
+// BNAP (data gradient behind a train-mode BatchNorm): the operand x is gx, the gradient BEFORE the BatchNorm-backward
+// affine; dy = A[t][c] * gx + B[t][c] * y + C[t][c] (the statement of snn_bn_bwd_apply, t = image / frames per step) is
+// formed when a staging pass has landed - one pass per tap, behind that tap's MFMAs - stored to dy_out for the cells
+// the tile owns (the weight gradient reads it) and split into the LDS image.  The separate apply pass over the layer
+// (12 bytes per element) disappears; coefficients of the <= 3 timesteps a halo can touch are staged in LDS once per block.
+constexpr int BN_NT = 3;      // timesteps of coefficients a block stages
+constexpr int BN_CMAX = 128;  // input channels (K) the BNAP variant supports
+
+template <int CO, bool F16, int ABL = 0, bool BNAP = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
                                                            const unsigned char* __restrict__ wimg,
                                                            float* __restrict__ y, HaloGeom g,
                                                            const float* __restrict__ addend,
-                                                           const float* __restrict__ addend2) {
+                                                           const float* __restrict__ addend2,
+                                                           const float* __restrict__ bn_y = nullptr,
+                                                           const float* __restrict__ bn_coef = nullptr,
+                                                           float* __restrict__ dy_out = nullptr) {
     constexpr int WM = 2, WN = 2, TM = 2, TN = CO / 64;
     constexpr int BTILE = (CO / 32) * 4096;     // bytes of one k-step's weight tile
     constexpr int NDMA = (CO / 32) * 4 / 4;     // 1-KiB LDS-DMA pieces per wave and k-step
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE];   // ONE array: 52 / 68 KiB
+    constexpr int CF_BYTES = BNAP ? 3 * BN_NT * BN_CMAX * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE + CF_BYTES];   // ONE array
     unsigned char* Aimg = smem;                        // [2 pieces][HCELLS][64 B]
     unsigned char* Bimg = smem + 2 * HPIECE;           // [2 buffers][BTILE]
+    [[maybe_unused]] float* Cf = reinterpret_cast<float*>(smem + 2 * HPIECE + 2 * BTILE);   // [3 planes][BN_NT][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +148,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * 4;
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x + (int64_t)nb * ipix * g.ldx), 0, xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_y = rs_x, rs_dy = rs_x;
+    [[maybe_unused]] const int t_lo = BNAP ? nb / g.bn_fps : 0;
+    [[maybe_unused]] int cofs[NPASS];      // BNAP: float offset of (timestep of the cell, channel quad) inside a coefficient plane
+    [[maybe_unused]] unsigned imask = 0;   // BNAP: bit p = the cell of pass p belongs to the tile (its dy is stored)
+    if constexpr (BNAP) {   // gx, y and dy_out are dense tensors of one layout (host-checked): one set of offsets
+        rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn_y + (int64_t)nb * ipix * g.ldx), 0,
+                                                 xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+        rs_dy = __builtin_amdgcn_make_buffer_rsrc(dy_out + (int64_t)nb * ipix * g.ldx, 0,
+                                                  xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+        for (int idx = tid; idx < 3 * BN_NT * g.Cin; idx += kThreads) {
+            const int pl = idx / (BN_NT * g.Cin), rem = idx - pl * BN_NT * g.Cin;
+            const int k = rem / g.Cin, c = rem - k * g.Cin;
+            const int t = t_lo + k < g.bn_T ? t_lo + k : g.bn_T - 1;
+            Cf[idx] = bn_coef[(int64_t)pl * g.bn_tc + (int64_t)t * g.Cin + c];
+        }
+    }
     unsigned voff[NPASS];
     int awr[NPASS];      // LDS byte offset (inside a piece) this thread writes for pass p
 #pragma unroll
@@ -152,6 +182,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
         const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
         voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;   // >= 2 GiB: range check -> zeros
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
+        if constexpr (BNAP) {
+            int ts = ok ? n / g.bn_fps - t_lo : 0;
+            ts = ts < BN_NT ? ts : BN_NT - 1;   // (never taken for host-accepted shapes)
+            cofs[p] = ts * g.Cin + quad * 4;
+            const int m = cell - (g.PW + 1);
+            imask |= (ok && m >= 0 && m < HBM_ && m < g.group_cells - c0) ? 1u << p : 0u;
+        }
     }
 
     // ---- fragment addressing
@@ -190,6 +227,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
             *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
         }
+    };
+
+    // BNAP: gx -> dy for one landed pass (the statement of k_bn_bwd_apply, same roundings) and the store of the tile's own cells
+    [[maybe_unused]] f32x4 pfy[2];
+    [[maybe_unused]] auto bn_combine = [&](f32x4& gxv, const f32x4& yv, int p, int chan_floats, bool live) {
+        const int planes = BN_NT * g.Cin;
+        const float* cf = Cf + cofs[p] + chan_floats;
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(cf), cb = *reinterpret_cast<const f32x4*>(cf + planes),
+                    cc = *reinterpret_cast<const f32x4*>(cf + 2 * planes);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gxv[e] = ca[e] * gxv[e] + cb[e] * yv[e] + cc[e];
+        const unsigned so = (live && ((imask >> p) & 1u)) ? voff[p] + (unsigned)chan_floats * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gxv), rs_dy, (int)so, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -246,6 +296,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 #pragma unroll
     for (int p = 0; p < NPASS; ++p)
         pf[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[p], 0, 0));
+    if constexpr (BNAP) {
+        f32x4 py[NPASS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+            py[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)voff[p], 0, 0));
+        __syncthreads();   // the coefficient planes are staged
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) bn_combine(pf[p], py[p], p, 0, true);
+    }
     store_halo();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -267,17 +326,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             if constexpr (!(ABL & 4))
                 pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                          rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            if constexpr (BNAP)
+                pfy[tap & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              rs_y, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
             kstep((kh - 1) * g.PW + (kw - 1), Bimg + cur * BTILE);
             // this wave's share of the next weight tile has landed (all but the youngest vector-memory operation are
             // done); the barrier makes every wave's share visible and retires this step's reads of the current buffer
             // (lgkmcnt(0): this wave's fragment reads have really left the LDS before another wave may overwrite them)
-            if constexpr (ABL & 2) asm volatile("" ::: "memory");
+            if constexpr (BNAP) {
+                // the pass requested during the PREVIOUS tap has landed (it is older than this tap's weight DMA, which this
+                // k-step's MFMAs have covered): gx -> dy in place, dy stored for the tile's own cells.  Behind it the queue
+                // holds this tap's two loads and that store: the weight DMA is the fourth-youngest operation.
+                const int pp = tap >= 1 ? tap - 1 : 0;   // (static after unrolling)
+                __builtin_amdgcn_sched_barrier(0);       // not above the MFMAs: its wait would expose this tap's DMA
+                if (tap >= 1) bn_combine(pf[pp], pfy[pp & 1], pp, more ? (chunk + 1) * 32 : 0, more);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap >= 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else if constexpr (ABL & 2) asm volatile("" ::: "memory");
             else if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (more) {   // every wave is past its last read of this chunk's halo image: swap in the next one
+            if constexpr (BNAP) bn_combine(pf[8], pfy[0], 8, (chunk + 1) * 32, true);
             store_halo();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -695,6 +768,7 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
     g.out_vec = (lddx % 4 == 0) && aligned16(dx) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = nullptr;
+    g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     hipLaunchKernelGGL((k_conv_s2dgrad3<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
                        static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
@@ -729,6 +803,61 @@ extern "C" int snn_weight_frag_image_batched(const float* flat_src, void* flat_d
         hipLaunchKernelGGL(k_weight_frag_image<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, flat_src,
                            static_cast<unsigned char*>(flat_dst), table, flip);
     SNN_CHECK_LAUNCH("snn_weight_frag_image_batched");
+    return 0;
+}
+
+extern "C" int snn_conv3x3_halo_bn_supported(int64_t N, int H, int W, int Cin, int Cout, int frames_per_step) {
+    // Cin: channels of gx / y / dy (the K dimension), Cout: channels of dx
+    if (!halo_shape_ok(N, H, W, Cin, Cout) || Cin > BN_CMAX || frames_per_step <= 0 || N % frames_per_step != 0) return 0;
+    if (Cout != 64 && Cout != 128) return 0;   // ONE channel tile: the block that computes dx also stores dy
+    // images a 288-cell halo can touch, and the timesteps they belong to: at most BN_NT
+    const int64_t images = HCELLS / ((int64_t)(H + 1) * (W + 1)) + 2;
+    return ((images + frames_per_step - 1) / frames_per_step + 1 <= BN_NT) ? 1 : 0;
+}
+
+extern "C" int snn_conv3x3_halo_bn(const float* gx, const float* y, const float* coef, int frames_per_step, float* dy_out,
+                                   const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W, int Cin,
+                                   int Cout, const float* addend, int64_t ld_addend, const float* addend2,
+                                   int64_t ld_addend2, void* stream) {
+    SNN_REQUIRE(gx && y && coef && dy_out && wt_image && dx, "snn_conv3x3_halo_bn: null pointer");
+    SNN_REQUIRE(snn_conv3x3_halo_bn_supported(N, H, W, Cin, Cout, frames_per_step),
+                "snn_conv3x3_halo_bn: shape not covered (N %lld, %dx%d, %d -> %d channels, %d frames per step; ask "
+                "snn_conv3x3_halo_bn_supported)", (long long)N, H, W, Cin, Cout, frames_per_step);
+    SNN_REQUIRE(lddx >= Cout, "snn_conv3x3_halo_bn: dx pixel stride smaller than channel count");
+    SNN_REQUIRE(aligned16(gx) && aligned16(y) && aligned16(dy_out) && aligned16(wt_image) && aligned16(coef),
+                "snn_conv3x3_halo_bn: operands must be 16-byte aligned");
+    SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv3x3_halo_bn: addend pixel stride smaller than channel count");
+    SNN_REQUIRE(!addend2 || ld_addend2 >= Cout, "snn_conv3x3_halo_bn: addend2 pixel stride smaller than channel count");
+    SNN_REQUIRE((int64_t)4 * H * W * Cin * 4 < 0x7fffffffLL, "snn_conv3x3_halo_bn: four images must span less than 2 GiB");
+    HaloGeom g;
+    g.ldx = Cin; g.ldy = lddx; g.ld_add = ld_addend; g.ld_add2 = ld_addend2;     // gx, y, dy_out: dense [N][H][W][Cin]
+    g.N = (int)N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.PW = W + 1; g.PH = H + 1;
+    g.G = (int)N;
+    const int64_t group_cells = (int64_t)g.G * g.PH * g.PW;
+    g.group_cells = (int)group_cells;
+    g.tiles_per_group = (int)snn_ceil_div(group_cells, HBM_);
+    g.tiles = g.tiles_per_group;
+    const int co_tile = Cout % 128 == 0 ? 128 : 64;
+    g.ntiles_n = Cout / co_tile;
+    // every channel tile would store the same dy: only ONE may, so the variant is for layers that fit one tile
+    SNN_REQUIRE(g.ntiles_n == 1, "snn_conv3x3_halo_bn: %d output channels need more than one channel tile", Cout);
+    g.tiles_per_xcd = (int)snn_ceil_div(g.tiles, 8);
+    g.magic_pw = magic_u32(g.PW); g.magic_ph = magic_u32(g.PH);
+    g.out_vec = (lddx % 4 == 0) && aligned16(dx) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
+                (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
+    g.bn_partial = nullptr;
+    g.OH = H; g.OW = W;
+    g.bn_fps = frames_per_step; g.bn_T = (int)(N / frames_per_step); g.bn_tc = g.bn_T * Cin;
+    dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8));
+    const unsigned char* wi = static_cast<const unsigned char*>(wt_image);
+    if (co_tile == 128)
+        hipLaunchKernelGGL((k_conv_halo3<128, false, 0, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, gx, wi, dx, g,
+                           addend, addend2, y, coef, dy_out);
+    else
+        hipLaunchKernelGGL((k_conv_halo3<64, false, 0, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, gx, wi, dx, g,
+                           addend, addend2, y, coef, dy_out);
+    SNN_CHECK_LAUNCH("snn_conv3x3_halo_bn");
     return 0;
 }
 
@@ -772,6 +901,7 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
                 (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = bn_partial;
     g.OH = H; g.OW = W;
+    g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
     if (bn_partial) bn_layout[0] = g.tiles_per_group;   // every slot of every step is written: rows_per_chunk stays 0
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     const unsigned char* wi = static_cast<const unsigned char*>(w_image);

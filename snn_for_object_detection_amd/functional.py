@@ -411,7 +411,7 @@ def _slot_of(param) -> Optional[GradSlot]:
 
 
 # ------------------------------------------------------------------------------------------- conv
-def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_image=None):
+def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_image=None, pend=None):
     """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
     (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
     T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
@@ -444,7 +444,14 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
         prev = acc[0].result
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
-    if (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
+    if pend is not None:
+        # (gy is gx here) dy = A*gx + B*y + C inside the halo-resident kernel, stored to pend[1] for the weight gradient
+        rec, dy_out = pend
+        if wt_image is None:
+            wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+        _hip.call("snn_conv3x3_halo_bn", rec.gx.data_ptr(), rec.y.data_ptr(), rec.coef.data_ptr(), B, dy_out.data_ptr(),
+                  wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cout, Cin, addend, ld_add, addend2, ld_add2, st)
+    elif (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
             and _hip.query("snn_conv3x3_s2_dgrad_supported", T * B, H, W, Cin, Ho, Wo, Cout)):
         # stride 2: all four phase classes of dx from ONE staged pass over dy (k_conv_s2dgrad3)
         if wt_image is None:
@@ -530,13 +537,17 @@ def _apply_pending(pend: PendingBnApply) -> None:
 
 
 def _wgrad_bn_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, pad: int) -> bool:
-    """The convolution's weight gradient can apply the BatchNorm-backward affine itself and nothing else needs dy."""
-    if not (USE_DEFERRED_BN_APPLY and weight.requires_grad and not x.requires_grad and x.dim() == 5):
+    """The convolution's backward can apply the BatchNorm-backward affine itself: its weight gradient when nothing else
+    needs dy (the event-frame layer), or its halo-resident data gradient (which also leaves dy for the weight gradient)."""
+    if not (USE_DEFERRED_BN_APPLY and weight.requires_grad and x.dim() == 5):
         return False
     T, B, Cin, H, W = x.shape
     Cout, _, KH, KW = weight.shape
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    return bool(_hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
+    if not x.requires_grad:
+        return bool(_hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
+    return (USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 1, 1) and _backward_precision == "bf16x3"
+            and bool(_hip.query("snn_conv3x3_halo_bn_supported", T * B, H, W, Cout, Cin, B)))
 
 
 class _Conv2d(Function):
@@ -617,7 +628,13 @@ class _Conv2d(Function):
                 if USE_WGRAD_STREAM:
                     _side_hold(stream, x, pend.gx, pend.y, pend.coef)
                 return None, None, None, None, None, None, None, None, None
-            _apply_pending(pend)   # this convolution takes a materialised dy after all
+            fused_dgrad = (ctx.needs_input_grad[0] and ctx.prec == _hip.PREC_BF16X3 and USE_HALO_CONV
+                           and (KH, KW, stride, pad) == (3, 3, 1, 1) and pend.dims == (T, B, Cout, Ho, Wo)
+                           and is_channels_last(pend.y)
+                           and _hip.query("snn_conv3x3_halo_bn_supported", T * B, H, W, Cout, Cin, B))
+            if not fused_dgrad:
+                _apply_pending(pend)   # this convolution takes a materialised dy after all
+                pend = None
         if ctx.needs_input_grad[0]:
             wref = ctx.weight_ref
             wt16 = wt_img = None
@@ -629,7 +646,15 @@ class _Conv2d(Function):
             else:
                 wt = torch.empty((Cin, KH, KW, Cout), device=x.device, dtype=_F32)
                 _hip.call("snn_weight_transpose", w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, st)
-            dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img)
+            if pend is not None:
+                # dy is formed inside the data-gradient kernel from (gx, y, coef) and left in `gy_new` for the weight gradient
+                gy_new = torch.empty_like(pend.gx)
+                dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img,
+                                       pend=(pend, gy_new))
+                gy = _cl_view(gy_new)
+                ldg = cl_stride(gy)
+            else:
+                dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
             if ctx.slot is not None and USE_WGRAD_STREAM:
