@@ -152,6 +152,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     [[maybe_unused]] const int t_lo = BNAP ? nb / g.bn_fps : 0;
     [[maybe_unused]] int cofs[NPASS];      // BNAP: float offset of (timestep of the cell, channel quad) inside a coefficient plane
     [[maybe_unused]] unsigned imask = 0;   // BNAP: bit p = the cell of pass p belongs to the tile (its dy is stored)
+    [[maybe_unused]] unsigned vmask = 0;   // BNAP: bit p = the cell of pass p is an image pixel (pad cells stay ZERO: the
+                                           // affine's constant term must not leak into the convolution's zero padding)
     if constexpr (BNAP) {   // gx, y and dy_out are dense tensors of one layout (host-checked): one set of offsets
         rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bn_y + (int64_t)nb * ipix * g.ldx), 0,
                                                  xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             cofs[p] = ts * g.Cin + quad * 4;
             const int m = cell - (g.PW + 1);
             imask |= (ok && m >= 0 && m < HBM_ && m < g.group_cells - c0) ? 1u << p : 0u;
+            vmask |= ok ? 1u << p : 0u;
         }
     }
 
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                     cc = *reinterpret_cast<const f32x4*>(cf + 2 * planes);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gxv[e] = ca[e] * gxv[e] + cb[e] * yv[e] + cc[e];
+        if (!((vmask >> p) & 1u)) gxv = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned so = (live && ((imask >> p) & 1u)) ? voff[p] + (unsigned)chan_floats * 4u : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gxv), rs_dy, (int)so, 0, 0);
     };

@@ -58,10 +58,14 @@ class BlockGen(nn.Module):
     concatenates them on channels; nested lists become nested ``BlockGen``s.
     """
 
-    def __init__(self, in_channels: int, cfgs: ListGen):
+    def __init__(self, in_channels: int, cfgs: ListGen, in_unbounded: bool = False):
+        """``in_unbounded`` (internal): the block input may exceed the fp16 x 3 range contract (it comes, possibly through
+        convolutions, pools, merges or nested blocks, from ReLU / SiLU / SumPool / ConvLSTM with no BatchNorm, spiking neuron
+        or Tanh in between); ``out_unbounded`` says the same of the block output."""
         super().__init__()
         self.in_channels = in_channels
         self.out_channels = 0
+        self.out_unbounded = False
         if isinstance(cfgs, Residual):
             self.merge = "residual"
         elif isinstance(cfgs, Dense):
@@ -74,7 +78,8 @@ class BlockGen(nn.Module):
         self.branch_state: List[List[bool]] = []
         self._branch_channels: List[int] = []
         for branch_cfg in cfgs:
-            layers, flags, channels = self._make_branch(in_channels, branch_cfg)
+            layers, flags, channels, unb = self._make_branch(in_channels, branch_cfg, in_unbounded)
+            self.out_unbounded = self.out_unbounded or unb   # a sum / concatenation is bounded only if every branch is
             branch_list.append(layers)
             self.branch_state.append(flags)
             self._branch_channels.append(channels)
@@ -107,25 +112,34 @@ class BlockGen(nn.Module):
                     break
 
     # ------------------------------------------------------------------ construction
-    def _make_branch(self, in_channels: int, cfg: ListGen) -> Tuple[nn.ModuleList, List[bool], int]:
+    def _make_branch(self, in_channels: int, cfg: ListGen, unbounded: bool = False):
         state_layers: List[bool] = []
         layer_list: List[nn.Module] = []
         channels = in_channels
         for layer_gen in cfg:
             if isinstance(layer_gen, list):
-                layer = BlockGen(channels, layer_gen)
+                layer = BlockGen(channels, layer_gen, in_unbounded=unbounded)
                 channels = layer.out_channels
             else:
                 layer, channels = layer_gen.get(channels)
             # fp16x3 (the default forward arithmetic) has a range contract (|x| < 4094) that spikes, sums of spikes and
-            # normalised activations meet by construction; a convolution fed by an unbounded activation takes the
-            # any-range bf16x6 arithmetic instead (unless the description set a precision itself)
-            if (isinstance(layer, HipConv2d) and layer.forward_precision is None and layer_list
-                    and isinstance(layer_list[-1], (HipReLU, HipSiLU, SumPool2d, ConvLSTM))):
+            # normalised activations meet by construction; a convolution whose input is not PROVABLY bounded - an
+            # unbounded activation (ReLU / SiLU / SumPool / ConvLSTM) upstream with no BatchNorm, spiking neuron or Tanh
+            # since, through any chain of convolutions, pools, passes, merges, nested blocks - takes the any-range bf16x6
+            # arithmetic instead (unless the description set a precision itself)
+            if isinstance(layer, HipConv2d) and layer.forward_precision is None and unbounded:
                 layer.forward_precision = "bf16x6"
+            if isinstance(layer, BlockGen):
+                unbounded = layer.out_unbounded
+            elif isinstance(layer, (HipReLU, HipSiLU, SumPool2d, ConvLSTM)):
+                unbounded = True
+            elif isinstance(layer, (HipBatchNorm2d, HipTanh)) or isinstance(_neuron_cell(layer), LIFCell):
+                unbounded = False
+            # everything else (convolutions, pools, up-sampling, pass, LI / SLI / Synapse integrators, Return) hands the
+            # status of its input on
             layer_list.append(layer)
             state_layers.append(_is_module_stateful(layer))
-        return nn.ModuleList(layer_list), state_layers, channels
+        return nn.ModuleList(layer_list), state_layers, channels, unbounded
 
     def _account_channels(self, channels: int) -> None:
         if self.merge == "residual":

@@ -263,3 +263,87 @@ def test_one_pass_stride2_data_gradient_against_fp64(H_, N, H, W, Cin, Cout):
     _hip.call("snn_conv3x3_s2_dgrad", gyd.data_ptr(), Cout, img_t.data_ptr(), dx2.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
               a1.data_ptr(), Cin, None, 0, st)
     assert torch.equal(dx2, dx + a1)
+
+
+@pytest.mark.parametrize("T,B,H,W,C,Cdx", [(4, 5, 30, 38, 128, 128), (3, 2, 60, 76, 64, 64), (6, 5, 8, 10, 128, 128),
+                                          (5, 3, 15, 19, 64, 128)])
+def test_halo_data_gradient_with_fused_batchnorm_apply(H_, T, B, H, W, C, Cdx):
+    """snn_conv3x3_halo_bn: dy = A*gx + B*y + C formed while gx is staged.  dy_out must equal snn_bn_bwd_apply's result
+    bit for bit (same statement, same roundings) and dx the plain halo-resident data gradient of that dy, bit for bit -
+    with a fused addend, timesteps changing inside a tile (small images) and cells no tile owns (pad cells)."""
+    _hip = H_
+    N = T * B
+    assert _hip.query("snn_conv3x3_halo_bn_supported", N, H, W, C, Cdx, B) == 1
+    torch.manual_seed(T * 10 + B)
+    st = torch.cuda.current_stream().cuda_stream
+    gx = torch.randn(N, H, W, C, device="cuda")
+    y = torch.randn(N, H, W, C, device="cuda")
+    coef = torch.randn(3, T, C, device="cuda")
+    wt = torch.randn(Cdx, 3, 3, C, device="cuda") / (9 * C) ** 0.5            # [Cin][KH][KW][Cout] of the layer
+    img = _image(_hip, wt, Cdx, C, 1, _hip.PREC_BF16X3)
+    add = torch.randn(N, H, W, Cdx, device="cuda")
+    # reference: the separate apply pass, then the plain kernel
+    dy_ref = torch.empty_like(gx)
+    _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), C, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+              dy_ref.data_ptr(), C, T, B * H * W, C, 0, st)
+    dx_ref = torch.empty(N, H, W, Cdx, device="cuda")
+    _hip.call("snn_conv3x3_halo", dy_ref.data_ptr(), C, img.data_ptr(), dx_ref.data_ptr(), Cdx, N, H, W, C, Cdx, add.data_ptr(),
+              Cdx, None, 0, None, 0, None, _hip.PREC_BF16X3, st)
+    dy_out = torch.full_like(gx, float("nan"))
+    dx = torch.full_like(dx_ref, float("nan"))
+    _hip.call("snn_conv3x3_halo_bn", gx.data_ptr(), y.data_ptr(), coef.data_ptr(), B, dy_out.data_ptr(), img.data_ptr(),
+              dx.data_ptr(), Cdx, N, H, W, C, Cdx, add.data_ptr(), Cdx, None, 0, st)
+    assert torch.equal(dy_out, dy_ref)        # every cell stored exactly once, by the tile that owns it
+    assert torch.equal(dx, dx_ref)
+    # against fp64 too (independent of the kernels above)
+    dy64 = (coef[0].double().repeat_interleave(B, 0)[:, None, None, :] * gx.double()
+            + coef[1].double().repeat_interleave(B, 0)[:, None, None, :] * y.double()
+            + coef[2].double().repeat_interleave(B, 0)[:, None, None, :])
+    xr = torch.zeros(N, Cdx, H, W, dtype=torch.float64, device="cuda", requires_grad=True)
+    w_ohwi = wt.permute(3, 1, 2, 0).double()                                      # [Cout][KH][KW][Cin]
+    F.conv2d(xr, w_ohwi.permute(0, 3, 1, 2), padding=1).backward(dy64.permute(0, 3, 1, 2))
+    assert rel_err(dx - add, xr.grad.permute(0, 2, 3, 1)) < 5e-5
+
+
+def test_deferred_batchnorm_apply_in_bottleneck_layers_is_bit_identical(H_):
+    """Module level: a stack whose 3x3 convolutions sit behind train-mode BatchNorms, with the deferred apply on and off
+    (functional.USE_DEFERRED_BN_APPLY): input gradient and every parameter gradient equal bit for bit; the apply launches
+    of the covered layers are gone."""
+    from snn_for_object_detection_amd import BlockGen, Conv, LIF, Norm, _hip
+    from snn_for_object_detection_amd import functional as HF
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 3, 2, 15, 19
+    x = (torch.rand(T, B, 64, H, W, device="cuda") < 0.3).float()
+    calls = []
+    real_call = _hip.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+
+    res = {}
+    for fused in (True, False):
+        HF.USE_DEFERRED_BN_APPLY = fused
+        try:
+            torch.manual_seed(12)
+            blk = BlockGen(64, [Conv(64, 3), Norm(), LIF(), Conv(128, 3), Norm(), LIF(), Conv(128, 3), Norm(), LIF()])
+            blk = blk.cuda().train()
+            tr = FlatTrainer(blk, lr=1e-3)
+            tr.zero_grad()
+            xin = x.clone().requires_grad_()
+            calls.clear()
+            _hip.call = spy
+            try:
+                out, _ = blk(xin)
+                (out * torch.linspace(0.5, 1.5, out.numel(), device="cuda").view(out.shape)).mean().backward()
+            finally:
+                _hip.call = real_call
+            tr.synchronize()
+            res[fused] = (xin.grad.clone(), tr.flat_grad.clone(), list(calls))
+            assert not HF._PENDING_APPLY
+        finally:
+            HF.USE_DEFERRED_BN_APPLY = True
+    # layers 2 and 3 (64 -> 128, 128 -> 128: ONE channel tile of dx) fuse; layer 1's dx has 64 channels: it fuses too
+    assert res[True][2].count("snn_conv3x3_halo_bn") == 3 and res[True][2].count("snn_bn_bwd_apply") == 0
+    assert res[False][2].count("snn_conv3x3_halo_bn") == 0 and res[False][2].count("snn_bn_bwd_apply") == 3
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])

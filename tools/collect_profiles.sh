@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (in the container, after gpurun merged the outputs): bash tools/collect_profiles.sh gpurun_out/<tag> <config> [round]
 # copies what tools/profile_round.sh wrote into profiles/ under the names DESIGN.md / bench.py refer to
-src=$1; cfg=$2; r=${3:-r02}
+src=$1; cfg=$2; r=${3:-r03}
 set -e
 cp $src/bench.json profiles/${r}_bench_${cfg}.json
 cp $src/kernel_table.txt profiles/${r}_bench_${cfg}_kernel_table.txt

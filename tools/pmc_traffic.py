@@ -26,6 +26,11 @@ def family(name: str) -> str:
     if base == "k_conv_gather":  # <BN, WM, WN, DGRAD, VEC, ...>: the first five arguments, as profiler.py labels them
         t = re.search(r"k_conv_gather<([^>]*)>", name)
         return f"k_conv_gather<{', '.join(a.strip() for a in t.group(1).split(',')[:5])}>" if t else base
+    if base == "k_conv_halo3":  # <CO, F16, ABL, BNAP>: forward (fp16 pieces) or data gradient, as profiler.py labels them
+        t = re.search(r"k_conv_halo3<(\d+), (true|false)", name)
+        return f"k_conv_halo3<{t.group(1)}, {'fwd' if t.group(2) == 'true' else 'dgrad'}>" if t else base
+    if base == "k_conv_s2dgrad3":
+        return "k_conv_s2dgrad3<dgrad>"
     if base == "k_conv_first":  # <CIN, KS, WGRAD>: the weight-gradient instance belongs to snn_conv2d_wgrad
         return "k_conv_wgrad" if re.search(r"k_conv_first<[^>]*true>", name) else "k_conv_first<2, 3, false>"
     if base.startswith("k_conv_wgrad") or base == "k_wgrad_reduce":
@@ -59,8 +64,12 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import csrc_fingerprint
     rows = dict(out)
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # steps the profiled command ran (warm-up included)
+    total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows.values())
     out["_meta"] = {"csrc_sha256": csrc_fingerprint(), "units": "bytes per launch; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024",
-                    "passes": [os.path.basename(os.path.dirname(a)) for a in sys.argv[1:3]]}
+                    "passes": [os.path.basename(os.path.dirname(a)) for a in sys.argv[1:3]],
+                    "profiled_steps": steps, "hbm_bytes_all_kernels": total,
+                    "hbm_bytes_per_step": total / steps if steps else None}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:16]:
         print(f"{k:52s} n={v['launches']:5d}  read {v['read_bytes_per_launch'] / 1e6:9.1f} MB  "
