@@ -63,6 +63,7 @@ struct HaloGeom {
     double* bn_partial;         // forward statistics partials [t][c][chunk][2] (null: none); chunk = tile of the group
     int OH, OW;                 // k_conv_s2dgrad3 only: size of the produced tensor dx (the strip grid H x W is dy's)
     int bn_T, bn_tc, bn_fps;    // BNAP: timesteps, T * Cin (distance of the coefficient planes), frames per timestep
+    int tiles_x, tiles_img;     // RECT: 4 x 32 pixel tiles per image row, tiles per image
 };
 
 __device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -106,7 +107,13 @@ __device__ __forceinline__ int cell_slot_off(int cell, int slot) { return cell *
 constexpr int BN_NT = 3;      // timesteps of coefficients a block stages
 constexpr int BN_CMAX = 128;  // input channels (K) the BNAP variant supports
 
-template <int CO, bool F16, int ABL = 0, bool BNAP = false>
+// RECT (rows longer than 78 pixels: the halo of a 128-cell strip tile would not fit): a block owns a 4 x 32 pixel
+// rectangle of ONE image instead; the LDS image is its 6 x 34 halo (204 cells, row pitch 34), a row tile of the MFMA is
+// one rectangle row = 32 consecutive cells again (conflict-free reads as in strip order), taps are offsets
+// (kh-1)*34 + (kw-1).  Everything else - chunk staging, weight DMA, epilogue - is the strip kernel's.
+constexpr int RTH = 4, RTW = 32, RPITCH = RTW + 2, RCELLS = (RTH + 2) * RPITCH;
+
+template <int CO, bool F16, int ABL = 0, bool BNAP = false, bool RECT = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
                                                            const unsigned char* __restrict__ wimg,
                                                            float* __restrict__ y, HaloGeom g,
@@ -135,12 +142,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     const int tile = (blockIdx.x & 7) * g.tiles_per_xcd + bq / g.ntiles_n;
     if (tile >= g.tiles) return;   // padding block of the last XCD share (whole block, before any barrier)
     const int n0c = (bq % g.ntiles_n) * CO;                     // first output channel of this block
-    const int grp = tile / g.tiles_per_group, kt = tile - grp * g.tiles_per_group;
-    const int c0 = kt * HBM_;                                   // first cell of the tile inside its group
-    const int R0g = c0 / g.PW, x0 = c0 - R0g * g.PW;            // its strip row inside the group, its column
-    const int ng = R0g / g.PH, y0 = R0g - ng * g.PH;
-    const int n0 = grp * g.G + ng;                              // image of the tile's first cell
-    const int nb = n0 > 0 ? n0 - 1 : 0;                         // base image of the buffer resource
+    int grp, kt, c0 = 0, x0 = 0, y0 = 0, n0, nb;
+    [[maybe_unused]] int ty = 0, tx = 0;
+    if constexpr (RECT) {
+        n0 = tile / g.tiles_img;                                // the tile's image
+        const int rem = tile - n0 * g.tiles_img;
+        ty = rem / g.tiles_x;
+        tx = rem - ty * g.tiles_x;
+        grp = n0 / g.G;
+        kt = (n0 - grp * g.G) * g.tiles_img + rem;              // chunk slot of the statistics partials
+        nb = n0;
+    } else {
+        grp = tile / g.tiles_per_group;
+        kt = tile - grp * g.tiles_per_group;
+        c0 = kt * HBM_;                                         // first cell of the tile inside its group
+        const int R0g = c0 / g.PW;                              // its strip row inside the group
+        x0 = c0 - R0g * g.PW;                                   // ... and its column
+        const int ng = R0g / g.PH;
+        y0 = R0g - ng * g.PH;
+        n0 = grp * g.G + ng;                                    // image of the tile's first cell
+        nb = n0 > 0 ? n0 - 1 : 0;                               // base image of the buffer resource
+    }
+    const int pitch = RECT ? RPITCH : g.PW;                     // cells per row of the LDS halo image
 
     // ---- halo loader: thread (cell = pass * 32 + tid / 8, channel quad = tid % 8)
     const int quad = tid & 7;
@@ -171,16 +194,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int cell = p * 32 + (tid >> 3);
-        // cell c of the halo is strip cell (tile start) + c - PW - 1; counted from column 0 of strip row R0 - 2:
-        const unsigned u = (unsigned)(x0 + cell + g.PW - 1);
-        const unsigned dR = udiv_small(u, g.magic_pw);
-        const int xx = (int)(u - dR * g.PW);
-        // ... and from row 0 of image n0 - 1:
-        const unsigned v = (unsigned)(y0 + (int)dR + g.PH - 2);
-        const unsigned dn = udiv_small(v, g.magic_ph);
-        const int yy = (int)(v - dn * g.PH);
-        const int n = n0 - 1 + (int)dn;
-        const bool ok = n >= 0 && n < g.N && xx < g.W && yy < g.H;
+        int xx, yy, n;
+        bool ok;
+        if constexpr (RECT) {
+            const int rr = cell / RPITCH, cc = cell - rr * RPITCH;
+            yy = ty * RTH - 1 + rr;
+            xx = tx * RTW - 1 + cc;
+            n = n0;
+            ok = cell < RCELLS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+        } else {
+            // cell c of the halo is strip cell (tile start) + c - PW - 1; counted from column 0 of strip row R0 - 2:
+            const unsigned u = (unsigned)(x0 + cell + g.PW - 1);
+            const unsigned dR = udiv_small(u, g.magic_pw);
+            xx = (int)(u - dR * g.PW);
+            // ... and from row 0 of image n0 - 1:
+            const unsigned v = (unsigned)(y0 + (int)dR + g.PH - 2);
+            const unsigned dn = udiv_small(v, g.magic_ph);
+            yy = (int)(v - dn * g.PH);
+            n = n0 - 1 + (int)dn;
+            ok = n >= 0 && n < g.N && xx < g.W && yy < g.H;
+        }
         const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
         voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;   // >= 2 GiB: range check -> zeros
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
@@ -188,8 +221,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             int ts = ok ? n / g.bn_fps - t_lo : 0;
             ts = ts < BN_NT ? ts : BN_NT - 1;   // (never taken for host-accepted shapes)
             cofs[p] = ts * g.Cin + quad * 4;
-            const int m = cell - (g.PW + 1);
-            imask |= (ok && m >= 0 && m < HBM_ && m < g.group_cells - c0) ? 1u << p : 0u;
+            bool mine;
+            if constexpr (RECT) {
+                const int rr = cell / RPITCH, cc = cell - rr * RPITCH;
+                mine = rr >= 1 && rr <= RTH && cc >= 1 && cc <= RTW;
+            } else {
+                const int m = cell - (g.PW + 1);
+                mine = m >= 0 && m < HBM_ && m < g.group_cells - c0;
+            }
+            imask |= (ok && mine) ? 1u << p : 0u;
             vmask |= ok ? 1u << p : 0u;
         }
     }
@@ -197,7 +237,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     // ---- fragment addressing
     int cellbase[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) cellbase[i] = g.PW + 1 + (wm * TM + i) * 32 + r;
+    for (int i = 0; i < TM; ++i)
+        cellbase[i] = RECT ? (wm * TM + i + 1) * RPITCH + 1 + r : g.PW + 1 + (wm * TM + i) * 32 + r;
     const int nchunks = g.Cin >> 5;
     const int co_tiles = g.Cout >> 5;
     // weight image: [tap][chunk][co tile][k16][piece][lane] x 16 B; this wave copies pieces wave, wave + 4, ...
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                                                               rs_y, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            kstep((kh - 1) * g.PW + (kw - 1), Bimg + cur * BTILE);
+            kstep((kh - 1) * pitch + (kw - 1), Bimg + cur * BTILE);
             // this wave's share of the next weight tile has landed (all but the youngest vector-memory operation are
             // done); the barrier makes every wave's share visible and retires this step's reads of the current buffer
             // (lgkmcnt(0): this wave's fragment reads have really left the LDS before another wave may overwrite them)
@@ -383,14 +424,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
         for (int pass = 0; pass < 32 / RPP; ++pass) {
             const int row = pass * RPP + lrow;
             const int m = (wm * TM + i) * 32 + row;            // cell of the tile
-            const unsigned u = (unsigned)(x0 + m);
-            const unsigned dR = udiv_small(u, g.magic_pw);
-            const int xx = (int)(u - dR * g.PW);
-            const unsigned v = (unsigned)(y0 + (int)dR);
-            const unsigned dn = udiv_small(v, g.magic_ph);
-            const int yy = (int)(v - dn * g.PH);
-            const int n = n0 + (int)dn;
-            const bool ok = m < cells_left && xx < g.W && yy < g.H && n < g.N && nch < g.Cout;
+            int xx, yy, n;
+            bool ok;
+            if constexpr (RECT) {
+                yy = ty * RTH + (m >> 5);
+                xx = tx * RTW + (m & 31);
+                n = n0;
+                ok = yy < g.H && xx < g.W && nch < g.Cout;
+            } else {
+                const unsigned u = (unsigned)(x0 + m);
+                const unsigned dR = udiv_small(u, g.magic_pw);
+                xx = (int)(u - dR * g.PW);
+                const unsigned v = (unsigned)(y0 + (int)dR);
+                const unsigned dn = udiv_small(v, g.magic_ph);
+                yy = (int)(v - dn * g.PH);
+                n = n0 + (int)dn;
+                ok = m < cells_left && xx < g.W && yy < g.H && n < g.N && nch < g.Cout;
+            }
             f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
             if (!ok) continue;
             if constexpr (ABL & 8) {
@@ -716,14 +766,18 @@ __global__ void k_weight_frag_image(const float* __restrict__ flat_src, unsigned
 static unsigned magic_u32(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static bool halo_shape_ok(int64_t N, int H, int W, int Cin, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0) return false;
-    if (Cin % 32 != 0 || Cin < 32 || Cout % 64 != 0) return false;
-    if (W + 1 > 79) return false;                                  // halo of a 128-cell tile: 128 + 2*PW + 2 <= 288 cells
-    if (N * (int64_t)(H + 1) * (W + 1) >= 0x7fffffffLL) return false;   // strip cells of a group in 32 bits
-    return true;
+// 0: not covered, 1: padded-strip tiles (rows of <= 78 pixels), 2: 4 x 32 rectangles (any width)
+static int halo_mode(int64_t N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    if (Cin % 32 != 0 || Cin < 32 || Cout % 64 != 0) return 0;
+    if (W + 1 <= 79) {                                              // halo of a 128-cell tile: 128 + 2*PW + 2 <= 288 cells
+        if (N * (int64_t)(H + 1) * (W + 1) >= 0x7fffffffLL) return 0;   // strip cells of a group in 32 bits
+        return 1;
+    }
+    const int64_t tiles = N * snn_ceil_div(H, RTH) * snn_ceil_div(W, RTW);
+    return tiles < 0x7fffffffLL ? 2 : 0;
 }
-
+static bool halo_shape_ok(int64_t N, int H, int W, int Cin, int Cout) { return halo_mode(N, H, W, Cin, Cout) != 0; }
 
 static bool s2dgrad_shape_ok(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout) {
     // Cin: the layer's input channels (dx), Cout: its output channels (dy, the K dimension)
@@ -773,6 +827,7 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
                 (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = nullptr;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
+    g.tiles_x = g.tiles_img = 0;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     hipLaunchKernelGGL((k_conv_s2dgrad3<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
                        static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
@@ -786,7 +841,8 @@ extern "C" int snn_conv3x3_halo_supported(int64_t N, int H, int W, int Cin, int 
 
 // chunk slots per timestep of the statistics partials snn_conv3x3_halo writes (= its tiles per group)
 extern "C" int64_t snn_conv3x3_halo_bn_chunks(int frames_per_step, int H, int W) {
-    return snn_ceil_div((int64_t)frames_per_step * (H + 1) * (W + 1), HBM_);
+    if (W + 1 <= 79) return snn_ceil_div((int64_t)frames_per_step * (H + 1) * (W + 1), HBM_);
+    return (int64_t)frames_per_step * snn_ceil_div(H, RTH) * snn_ceil_div(W, RTW);
 }
 
 extern "C" size_t snn_weight_frag_image_bytes(int O, int I) { return (size_t)9 * O * I * 4; }
@@ -812,7 +868,7 @@ extern "C" int snn_weight_frag_image_batched(const float* flat_src, void* flat_d
 
 extern "C" int snn_conv3x3_halo_bn_supported(int64_t N, int H, int W, int Cin, int Cout, int frames_per_step) {
     // Cin: channels of gx / y / dy (the K dimension), Cout: channels of dx
-    if (!halo_shape_ok(N, H, W, Cin, Cout) || Cin > BN_CMAX || frames_per_step <= 0 || N % frames_per_step != 0) return 0;
+    if (halo_mode(N, H, W, Cin, Cout) != 1 || Cin > BN_CMAX || frames_per_step <= 0 || N % frames_per_step != 0) return 0;
     if (Cout != 64 && Cout != 128) return 0;   // ONE channel tile: the block that computes dx also stores dy
     // images a 288-cell halo can touch, and the timesteps they belong to: at most BN_NT
     const int64_t images = HCELLS / ((int64_t)(H + 1) * (W + 1)) + 2;
@@ -853,6 +909,7 @@ extern "C" int snn_conv3x3_halo_bn(const float* gx, const float* y, const float*
     g.bn_partial = nullptr;
     g.OH = H; g.OW = W;
     g.bn_fps = frames_per_step; g.bn_T = (int)(N / frames_per_step); g.bn_tc = g.bn_T * Cin;
+    g.tiles_x = g.tiles_img = 0;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8));
     const unsigned char* wi = static_cast<const unsigned char*>(wt_image);
     if (co_tile == 128)
@@ -889,12 +946,23 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     HaloGeom g;
     g.ldx = ldx; g.ldy = ldy; g.ld_add = ld_addend; g.ld_add2 = ld_addend2;
     g.N = (int)N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    const bool rect = halo_mode(N, H, W, Cin, Cout) == 2;
     g.PW = W + 1; g.PH = H + 1;
     g.G = bn_partial ? frames_per_step : (int)N;
-    const int64_t group_cells = (int64_t)g.G * g.PH * g.PW;
-    g.group_cells = (int)group_cells;
-    g.tiles_per_group = (int)snn_ceil_div(group_cells, HBM_);
-    const int64_t tiles = (int64_t)(N / g.G) * g.tiles_per_group;
+    g.tiles_x = (int)snn_ceil_div(W, RTW);
+    g.tiles_img = g.tiles_x * (int)snn_ceil_div(H, RTH);
+    int64_t tiles;
+    if (rect) {
+        g.group_cells = 0;
+        g.tiles_per_group = g.G * g.tiles_img;
+        tiles = N * (int64_t)g.tiles_img;
+        SNN_REQUIRE((int64_t)H * W * ldx * 4 < 0x7fffffffLL, "snn_conv3x3_halo: an image must span less than 2 GiB");
+    } else {
+        const int64_t group_cells = (int64_t)g.G * g.PH * g.PW;
+        g.group_cells = (int)group_cells;
+        g.tiles_per_group = (int)snn_ceil_div(group_cells, HBM_);
+        tiles = (int64_t)(N / g.G) * g.tiles_per_group;
+    }
     const int co_tile = Cout % 128 == 0 ? 128 : 64;
     g.ntiles_n = Cout / co_tile;
     SNN_REQUIRE(tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_halo: grid too large");
@@ -911,7 +979,14 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     const unsigned char* wi = static_cast<const unsigned char*>(w_image);
     const bool f16 = precision == SNN_PREC_FP16X3;
 #define SNN_HALO_LAUNCH(CO_, F16_)                                                                                   \
-    hipLaunchKernelGGL((k_conv_halo3<CO_, F16_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, addend2)
+    do {                                                                                                              \
+        if (rect)                                                                                                     \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, F16_, 0, false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, \
+                               y, g, addend, addend2, nullptr, nullptr, nullptr);                                     \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, F16_>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, wi, y, g, addend, \
+                               addend2, nullptr, nullptr, nullptr);                                                   \
+    } while (0)
 #ifdef SNN_TUNING
     if (const char* e = snn_tuning_env("SNN_HALO_ABL")) {   // timing experiments (tools/halo_abl.py): WRONG results
         const int abl = atoi(e);

@@ -522,6 +522,11 @@ class PendingBnApply(NamedTuple):
 
 _PENDING_APPLY = {}   # gx.data_ptr() -> PendingBnApply
 USE_DEFERRED_BN_APPLY = not os.environ.get("SNN_NO_DEFERRED_BN_APPLY")   # tuning / bisecting aid
+# The same inside the halo-resident DATA gradient (snn_conv3x3_halo_bn) is built and parity-tested but OFF by default:
+# measured (rocprofv3, profiles/r03_*) the fused kernel takes 390 us where data gradient + apply take ~300 us on the
+# 64-channel layers (both are near the HBM rate there and the fused form reads y through the halo overlap as well) and
+# 144 vs ~117 us on the 128-channel ones (the per-tap combine sits in front of every k-step's barrier).  DESIGN section 5.
+USE_DEFERRED_BN_APPLY_DGRAD = bool(os.environ.get("SNN_DEFERRED_BN_APPLY_DGRAD"))
 
 
 def reset_backward_state() -> None:
@@ -546,7 +551,8 @@ def _wgrad_bn_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, pad: int) -
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     if not x.requires_grad:
         return bool(_hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
-    return (USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 1, 1) and _backward_precision == "bf16x3"
+    return (USE_DEFERRED_BN_APPLY_DGRAD and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 1, 1)
+            and _backward_precision == "bf16x3"
             and bool(_hip.query("snn_conv3x3_halo_bn_supported", T * B, H, W, Cout, Cin, B)))
 
 

@@ -58,6 +58,11 @@ def work_of(name: str, a):
         flops = 2.0 * n * h * w * cout * 9 * cin
         byts = 4.0 * (n * h * w * cin + n * h * w * cout + cout * 9 * cin)
         return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, {'fwd' if prec == 4 else 'dgrad'}>", flops, byts
+    if name == "snn_conv3x3_halo_bn":   # the same data gradient with the BatchNorm-backward affine applied while staging
+        n, h, w, cin, cout = a[8], a[9], a[10], a[11], a[12]
+        flops = 2.0 * n * h * w * cout * 9 * cin
+        byts = 4.0 * (3 * n * h * w * cin + n * h * w * cout + cout * 9 * cin)   # gx, y read; dy, dx written
+        return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, dgrad>", flops, byts
     if name == "snn_conv3x3_s2_dgrad":   # one-pass stride-2 data gradient
         n, h, w, cin, ho, wo, cout = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         flops = 2.0 * n * ho * wo * cout * 9 * cin

@@ -143,6 +143,7 @@ class FlatTrainer:
         self._comm_stream = None
         self._flags_work = None
         self._flags = None
+        self._ones_flags = None
         if (overlap_grad_exchange and self.world > 1 and hasattr(model, "_snn_neck_grads_ready")
                 and all(hasattr(model, a) for a in ("neck_net", "head_net"))):
             # a SODa detector: neck + head gradients go out while the backbone's backward pass still runs
@@ -252,7 +253,15 @@ class FlatTrainer:
         hangs the ranks that took the other branch); only a rank that itself skipped a parameter reads the result."""
         written = [slot.written for slot in self.slots]
         if self.world > 1:
-            flags = torch.tensor(written, dtype=torch.int32, device=self.flat_grad.device)
+            if all(written):
+                # the common case never touches the host: a device-side copy of a cached all-ones vector (building the
+                # tensor from the Python list is a pageable host-to-device copy that stalls the launching thread until
+                # the stream has drained - once per step, in front of the gradient exchange)
+                if self._ones_flags is None:
+                    self._ones_flags = torch.ones(len(self.slots), dtype=torch.int32, device=self.flat_grad.device)
+                flags = self._ones_flags.clone()
+            else:
+                flags = torch.tensor(written, dtype=torch.int32, device=self.flat_grad.device)
             work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
             if all(written):
                 # whatever the other ranks did, the union is "all written": no host round trip.  The handle is kept

@@ -41,6 +41,11 @@ HALO_CASES = [
     (2, 33, 41, 96, 192),     # three chunks, three 64-wide channel tiles
     (1, 5, 6, 32, 256),       # two 128-wide channel tiles
     (4, 12, 70, 64, 128),     # tiles ending inside an image row
+    # rows longer than 78 pixels: 4 x 32 rectangles of one image (RECT) instead of strip tiles
+    (2, 24, 100, 64, 64),     # partial rectangles on the right edge (100 = 3 * 32 + 4)
+    (1, 7, 304, 64, 128),     # the deep-backbone row length, partial rectangles on the bottom edge (7 = 4 + 3)
+    (3, 33, 81, 32, 64),      # one chunk, 81 = 2 * 32 + 17
+    (2, 90, 160, 128, 128),   # a 1 Mpx neck map
 ]
 
 
@@ -117,7 +122,8 @@ def test_halo_channel_slices_and_fused_addends(H_):
 
 
 @pytest.mark.parametrize("T,B,H,W,Cin,Cout", [(3, 2, 30, 38, 64, 64), (4, 3, 15, 19, 128, 128), (5, 1, 8, 10, 64, 128),
-                                             (2, 5, 60, 76, 64, 64), (6, 2, 3, 4, 32, 64)])
+                                             (2, 5, 60, 76, 64, 64), (6, 2, 3, 4, 32, 64),
+                                             (3, 2, 13, 100, 64, 64), (2, 1, 21, 304, 64, 64)])   # the last two: RECT tiles
 def test_halo_batchnorm_statistics_partials(H_, T, B, H, W, Cin, Cout):
     """The partials the forward leaves for the BatchNorm behind it (per timestep, tiles never straddle two steps) give
     the sums of the stored values - against fp64 sums of y and against the separate statistics pass."""
@@ -167,9 +173,10 @@ def test_halo_refuses_uncovered_shapes(H_):
     x = torch.zeros(1, 4, 100, 64, device="cuda")
     img = torch.zeros(9 * 64 * 64, device="cuda")
     y = torch.zeros(1, 4, 100, 64, device="cuda")
-    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 64) == 0          # row longer than the halo window
+    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 32) == 0          # 32 output channels: the direct kernel
+    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 48, 64) == 0          # input channels not a multiple of 32
     with pytest.raises(RuntimeError, match="shape not covered"):
-        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 100, 64, 64, None, 0, None, 0,
+        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 100, 64, 32, None, 0, None, 0,
                   None, 0, None, _hip.PREC_FP16X3, st)
     with pytest.raises(RuntimeError, match="precision"):
         _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 50, 64, 64, None, 0, None, 0,
@@ -323,7 +330,7 @@ def test_deferred_batchnorm_apply_in_bottleneck_layers_is_bit_identical(H_):
 
     res = {}
     for fused in (True, False):
-        HF.USE_DEFERRED_BN_APPLY = fused
+        HF.USE_DEFERRED_BN_APPLY = HF.USE_DEFERRED_BN_APPLY_DGRAD = fused   # (the data-gradient form is opt-in)
         try:
             torch.manual_seed(12)
             blk = BlockGen(64, [Conv(64, 3), Norm(), LIF(), Conv(128, 3), Norm(), LIF(), Conv(128, 3), Norm(), LIF()])
@@ -342,7 +349,7 @@ def test_deferred_batchnorm_apply_in_bottleneck_layers_is_bit_identical(H_):
             res[fused] = (xin.grad.clone(), tr.flat_grad.clone(), list(calls))
             assert not HF._PENDING_APPLY
         finally:
-            HF.USE_DEFERRED_BN_APPLY = True
+            HF.USE_DEFERRED_BN_APPLY, HF.USE_DEFERRED_BN_APPLY_DGRAD = True, False
     # layers 2 and 3 (64 -> 128, 128 -> 128: ONE channel tile of dx) fuse; layer 1's dx has 64 channels: it fuses too
     assert res[True][2].count("snn_conv3x3_halo_bn") == 3 and res[True][2].count("snn_bn_bwd_apply") == 0
     assert res[False][2].count("snn_conv3x3_halo_bn") == 0 and res[False][2].count("snn_bn_bwd_apply") == 3

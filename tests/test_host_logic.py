@@ -77,7 +77,8 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 7, 120, 152, 64) == 0   # frames per step must divide N
     # ... and the halo-resident 3x3 kernel's layout (strip tiles of 128 cells per timestep), where that kernel applies
     assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 128) == 1
-    assert hip_lib.snn_conv3x3_halo_supported(160, 120, 152, 64, 64) == 0      # strip row longer than its halo window
+    assert hip_lib.snn_conv3x3_halo_supported(160, 120, 152, 64, 64) == 1      # long rows: 4 x 32 rectangles
+    assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 120, 152) == 5 * 30 * 5
     assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 32) == 0       # <= 32 output channels: direct kernel
     assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) == (5 * 31 * 39 + 127) // 128
     assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 5, 30, 38, 128) >= 32 * hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) * 128 * 2
