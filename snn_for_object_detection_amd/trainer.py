@@ -157,7 +157,11 @@ class FlatTrainer:
         has produced them (``early_all_reduce()``, called from a backward hook), while the rest of the backward pass
         still runs; ``step()`` then exchanges only what is left.  The parameters must form the TAIL of the flat buffer
         (for ``SODa``: neck + head = 93 % of TinyYolo, whose gradients are complete when the backward pass crosses the
-        backbone / neck boundary).  Returns the first flat index of the early part."""
+        backbone / neck boundary).  Returns the first flat index of the early part.
+
+        Assumes ONE backward pass per ``step()`` (the early part is summed over the ranks as soon as that pass has
+        produced it; a second backward pass would add local gradients onto already reduced ones): accumulate
+        micro-batches with ``FlatTrainer(..., overlap_grad_exchange=False)``."""
         ids = {id(p) for m in modules for p in m.parameters() if p.requires_grad}
         first = next((k for k, p in enumerate(self.params) if id(p) in ids), None)
         if first is None or any(id(p) not in ids for p in self.params[first:]) or len(ids) != len(self.params) - first:
