@@ -523,7 +523,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 // their class: kh = 1 -> even rows from dy row a; kh = 0 -> odd rows from dy row a + 1; kh = 2 -> odd rows from dy row a
 // (columns alike).  Four accumulator sets of 32 cells x 64 channels per wave (128 registers), 4 waves over the cells,
 // 64 dx channels per block.  The weight image is the stride-1 data-gradient image (mirrored taps): tap t is read at 8 - t.
-template <bool UNUSED = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __restrict__ x,   // dy
                                                               const unsigned char* __restrict__ wimg,
                                                               float* __restrict__ y,         // dx
@@ -646,7 +645,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
             pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                      rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int dummy = 0; (void)dummy;
             const int kh = tap / 3, kw = tap - 3 * kh;
             // kh = 1: even dx rows, dy row a; kh = 0: odd rows, dy row a + 1; kh = 2: odd rows, dy row a (columns alike)
             const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
@@ -829,7 +827,7 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
     g.tiles_x = g.tiles_img = 0;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
-    hipLaunchKernelGGL((k_conv_s2dgrad3<false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
+    hipLaunchKernelGGL(k_conv_s2dgrad3, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
                        static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
     SNN_CHECK_LAUNCH("snn_conv3x3_s2_dgrad");
     return 0;

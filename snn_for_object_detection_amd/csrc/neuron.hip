@@ -1414,6 +1414,9 @@ extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, co
     int64_t total = (int64_t)T * M * (C / vec);
     int64_t blocks = snn_ceil_div(total, kThreads);
     if (blocks > snn_max_blocks()) blocks = snn_max_blocks();
+    if (const char* force = snn_tuning_env("SNN_APPLY_CAP")) {   // tuning aid: blocks per launch of the apply pass
+        if (atoi(force) > 0 && blocks > atoi(force)) blocks = atoi(force);
+    }
     if (vec == 4)
         hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y,
                            ldy, coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);
