@@ -58,6 +58,8 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
                 or kernel.endswith(", true>")     # k_conv_direct3<BN, WM, WN, DGRAD>
                 or "dgrad" in kernel)             # k_conv_halo3<CO, dgrad>, k_conv_s2dgrad3
     prec = bwd_prec if backward else fwd_prec
+    if "bf16s" in kernel:   # bf16-storage mode: stored bf16 activations x bf16-rounded weights, one product
+        return PEAK_BF16_MATRIX_TFLOPS, "bf16 dense MFMA, one product (bf16 storage)"
     if prec == "bf16":
         return PEAK_BF16_MATRIX_TFLOPS, "bf16 dense MFMA, one product"
     if prec == "bf16x3":
@@ -242,6 +244,10 @@ def main():
                          "bf16 = the labelled THROUGHPUT mode (operands rounded to bf16, one product; not parity)")
     ap.add_argument("--backward-precision", choices=("bf16x3", "fp32", "bf16"), default="bf16x3",
                     help="arithmetic of the backward convolutions (bf16 = throughput mode, one product)")
+    ap.add_argument("--storage", choices=("fp32", "bf16"), default="fp32",
+                    help="activation storage: fp32 (default, the parity path) or bf16 - the labelled THROUGHPUT mode: wide "
+                         "tensors bf16 in HBM, bf16 products, fp32 state / accumulation (own tolerances: "
+                         "tests/test_gpu_bf16_storage.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
@@ -300,6 +306,8 @@ def main():
     _hip.load()
     S.functional.set_forward_precision(args.forward_precision)
     S.functional.set_backward_precision(args.backward_precision)
+    S.functional.set_activation_storage(args.storage)
+    sb = args.storage == "bf16"
 
     torch.manual_seed(2)  # same reference init on every rank
     X, labels = synthetic_batch(T, B, H, W, classes, device, seed=rank, p=cfg["p"])  # a different shard per rank
@@ -387,15 +395,17 @@ def main():
         total_ms = sum(r["ms"] for r in table.values())
         name, row = max(table.items(), key=lambda kv: kv[1]["ms"])
         default_shape = (T, B, H, W, classes) == (cfg["T"], cfg["batch"], cfg["H"], cfg["W"], cfg["classes"])
-        traffic, traffic_src = pmc_traffic(args.config, name) if default_shape else (None, {"note": "non-default shape"})
+        traffic, traffic_src = (pmc_traffic(args.config + ("_bf16s" if sb else ""), name) if default_shape
+                                else (None, {"note": "non-default shape"}))
         if name.startswith("k_conv"):
             peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
             head = {"bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
                     "unit": "TFLOP/s", "frac": row["tflops"] / peak}
         else:  # the fused norm + neuron scans and the other pointwise kernels move bytes: priced against HBM
             head = {"bound": "hbm", "kernel": name, "achieved": row["gbs"], "peak": PEAK_HBM_GBS,
-                    "peak_basis": "HBM3E 8 TB/s spec (6.3 TB/s measured copy rate); algorithmic bytes = 4 B per tensor "
-                                  "element the fused kernel must touch", "unit": "GB/s", "frac": row["gbs"] / PEAK_HBM_GBS}
+                    "peak_basis": f"HBM3E 8 TB/s spec (6.3 TB/s measured copy rate); algorithmic bytes = {2 if sb else 4} B per "
+                                  "tensor element the fused kernel must touch", "unit": "GB/s",
+                    "frac": row["gbs"] / PEAK_HBM_GBS}
         roofline = {
             **head, "traffic": traffic, "traffic_source": traffic_src,
             "achieved_tflops": row["tflops"], "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
@@ -434,12 +444,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             # fp32 tensors and fp32 accumulation in every mode; "f32" alone only when the products are exact fp32 too
-            "dtype": "f32" if exact else ("bf16 products, f32 accumulate / storage (throughput mode, not parity)"
+            "dtype": "bf16 storage + bf16 products, f32 state / accumulate (throughput mode, not parity)" if sb
+                     else "f32" if exact else ("bf16 products, f32 accumulate / storage (throughput mode, not parity)"
                                           if "bf16" in (args.forward_precision, args.backward_precision)
                                           else "f32 (16-bit split products)"),
-            "arithmetic_bits": {"storage": 32, "accumulate": 32,
-                                "forward_product": PRODUCT_BITS[args.forward_precision],
-                                "backward_product": PRODUCT_BITS[args.backward_precision]},
+            "arithmetic_bits": {"storage": 16 if sb else 32, "accumulate": 32,
+                                "forward_product": 8 if sb else PRODUCT_BITS[args.forward_precision],
+                                "backward_product": 8 if sb else PRODUCT_BITS[args.backward_precision]},
             "data": "synthetic",
             "config": {
                 "workload": f"{cfg['label']}, B={B}/GPU T={T}, p(event)={cfg['p']}, "
@@ -449,7 +460,11 @@ def main():
                 "name": args.config, "trainable_params": n_params,
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
                 "sync_batchnorm": bool(args.sync_bn and world > 1),
-                "arithmetic": "fp32 storage and accumulation; forward conv "
+                "storage": args.storage,
+                "arithmetic": "bf16 STORAGE of the activation tensors (conv outputs, spikes, saved potentials, gradients), "
+                              "fp32 neuron state / BatchNorm statistics / weights / accumulation; convolutions: stored bf16 "
+                              "activations x bf16-rounded weights, one MFMA product" if sb else
+                              "fp32 storage and accumulation; forward conv "
                               + {"fp16x3": "fp16x3 split products (two fp16 pieces per operand after exact 2^k "
                                            "pre-scaling, hh+hl+lh; fp32-grade: rel 5e-7 vs fp64, same as the fp32 MFMA)",
                                  "bf16x6": "bf16x6 split products (3-way bf16 split of both operands, fp32-grade: "

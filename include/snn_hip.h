@@ -62,16 +62,29 @@ enum {
  *                   and multiplied as it is - one product, fp32 accumulation, fp32 tensors in HBM.  Relative error
  *                   2^-9 per product: NOT a parity mode (spike trains diverge from the fp32 reference within a few
  *                   layers; loss and gradients to ~1e-2).  Never a default.                     fwd, dgrad, wgrad
+ *   SNN_PREC_BF16S  bf16 STORAGE (the opt-in throughput mode whose tensors are bf16 in HBM too): the activation
+ *                   operands AND results of the call (x / y, dy / dx; every `float*` activation pointer of the
+ *                   signature then addresses bf16 elements, pixel strides stay in ELEMENTS) are bf16, products are
+ *                   single bf16 MFMA products (weights, fp32, are rounded to bf16 on the way in), accumulation and
+ *                   BatchNorm statistics fp32 / fp64.  Weights, weight gradients, statistics, neuron state stay fp32.
+ *                   Same tolerances class as SNN_PREC_BF16X1; never a default.  Covered shapes: the vectorised
+ *                   (Cin % 32 == 0) implicit GEMM, the halo-resident 3x3 kernels, the event-frame kernels (input
+ *                   frames fp32).                                                              fwd, dgrad, wgrad
  * The mode is an argument of every call - the library keeps no process-wide arithmetic state. */
-enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4, SNN_PREC_BF16X1 = 5 };
+enum { SNN_PREC_FP32 = 0, SNN_PREC_BF16X3 = 1, SNN_PREC_BF16X6 = 3, SNN_PREC_FP16X3 = 4, SNN_PREC_BF16X1 = 5,
+       SNN_PREC_BF16S = 6 };
 
 /* flags of snn_affine_neuron_fwd / _bwd */
 enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even when one timestep of every tensor fits
                                         the 31-bit buffer offsets (the library switches by itself when it does not) */
-       SNN_SCAN_LAST_STEP_ONLY = 2   /* LIF / LI / LI+Tanh whose consumer keeps the last timestep only (the detection head,
+       SNN_SCAN_LAST_STEP_ONLY = 2,  /* LIF / LI / LI+Tanh whose consumer keeps the last timestep only (the detection head,
                                         soda.py:141-144): fwd writes out[M][ldo] of step T-1 instead of [T][M][ldo];
                                         bwd takes g_out[M][ldg] (and, LI+Tanh, the saved output [M][C]) of that step,
-                                        the output gradient of every earlier step being zero */ };
+                                        the output gradient of every earlier step being zero */
+       SNN_SCAN_BF16_STORAGE = 4     /* bf16-storage mode (see SNN_PREC_BF16S): the activation tensors of the call - fwd: y,
+                                        out, addend, vdec; bwd: g_out, state, y, gx - are bf16 (pointers passed as float*,
+                                        strides in elements); state (v, i), alpha / beta and the sums stay fp32.
+                                        NONE / LIF / LI / LI+Tanh, C and strides multiples of 4 */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
@@ -174,11 +187,11 @@ int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ld
  * four stride-phase classes of dx are produced from one staged dy halo instead of four launches that each gather dy
  * again.  wt_image = the layer's data-gradient image (snn_weight_frag_image_batched of the transposed weights, flip = 1,
  * SNN_PREC_BF16X3 - the image the stride-1 data gradient uses).  dx[N][H][W][lddx] (Cin channels) from dy[N][Ho][Wo][lddy]
- * (Cout channels), Ho = (H-1)/2 + 1; addend / addend2 as for snn_conv2d_dgrad.  bf16 x 3 arithmetic. */
+ * (Cout channels), Ho = (H-1)/2 + 1; addend / addend2 as for snn_conv2d_dgrad.  bf16 x 3 arithmetic, or bf16 storage. */
 int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout);
 int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W,
                          int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
-                         int64_t ld_addend2, void* stream);
+                         int64_t ld_addend2, int precision /* SNN_PREC_BF16X3 | SNN_PREC_BF16S */, void* stream);
 /* Data gradient of a 3x3 / stride 1 / pad 1 convolution behind a train-mode BatchNorm with the BatchNorm-backward affine
  * applied while gx is staged (k_conv_halo3<BNAP>): dy = A[t][c]*gx + B[t][c]*y + C[t][c] (see snn_conv2d_wgrad_bn; coef =
  * [3][T][Cin], T = N / frames_per_step) is formed once per staged cell, written to dy_out (dense [N][H][W][Cin], for the
@@ -324,6 +337,11 @@ int snn_bn_bwd_coef(const double* raw, const double* raw_local, double* param_su
 int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy,
                      const float* coefA, const float* coefB, const float* coefC,
                      float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate, void* stream);
+/* the same two passes on bf16 tensors (bf16-storage mode, see SNN_PREC_BF16S: gx / y / dy are bf16, coefficients and
+ * partials as above; C and the strides multiples of 4) */
+int snn_bn_bwd_apply_bf16(const float* gx, const float* y, int64_t ldy, const float* coefA, const float* coefB,
+                          const float* coefC, float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate, void* stream);
+int snn_bn_stats_bf16(const float* y, int64_t ldy, int T, int64_t M, int C, double* partial, void* stream);
 
 /* ---------------------------------------------------------------- merges and pointwise
  * Residual merge = torch.stack(out).sum(0) (generator.py:145-146); Dense merge = torch.cat(out,1)

@@ -16,8 +16,8 @@ NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE =
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 8
-PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1 = 0, 1, 3, 4, 5   # SNN_PREC_* of include/snn_hip.h
-SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY = 1, 2
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
+SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE = 1, 2, 4
 
 
 class NeuronParams(Structure):
@@ -46,7 +46,7 @@ SIGNATURES = {
     "snn_conv2d_wgrad_bn": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                     _P, _I, _P]),
     "snn_conv3x3_s2_dgrad_supported": (c_int, [_L, _I, _I, _I, _I, _I, _I]),
-    "snn_conv3x3_s2_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
+    "snn_conv3x3_s2_dgrad": (c_int, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P]),
     "snn_conv3x3_halo_bn_supported": (c_int, [_L, _I, _I, _I, _I, _I]),
     "snn_conv3x3_halo_bn": (c_int, [_P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P]),
     "snn_conv3x3_halo_supported": (c_int, [_L, _I, _I, _I, _I]),
@@ -78,6 +78,8 @@ SIGNATURES = {
                                       POINTER(NeuronParams), _I, _P]),
     "snn_bn_bwd_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
+    "snn_bn_bwd_apply_bf16": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
+    "snn_bn_stats_bf16": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_copy_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
     "snn_add_channels": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
     "snn_add": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),

@@ -28,6 +28,7 @@
 // The split modes keep the 1e-4 parity target against the CPU reference: see DESIGN.md section 3 for the measured
 // errors of each mode.
 #include <stdlib.h>
+#include <type_traits>
 #include "snn_common.h"
 
 #if defined(SNN_STAMP) || defined(SNN_CLOCK)
@@ -166,7 +167,10 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // per 4 consecutive k, 4 hi pieces then 4 lo pieces - the same 16 bytes at the same offsets), written once per optimiser
 // step; the loader is unchanged and the per-block conversion of the weight tile (half of the conversion VALU of a
 // k-step, repeated by every one of the ~1 400 blocks of a launch) disappears.  Same bits as converting on the fly.
-template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false>
+// SB (FAST, SPLIT 5 only; SNN_PREC_BF16S, the bf16-STORAGE throughput mode): `in`, `out` and the addends are bf16 tensors
+// (strides in elements).  The gathered rows arrive as 8-byte loads and go to LDS as they are - no conversion; the
+// epilogue rounds the fp32 accumulators to bf16 on their way out.  Weights stay fp32 and are rounded in the loader.
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false, bool SB = false>
 __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add,
@@ -175,6 +179,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
     constexpr int TN = BN / WN / 32;
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(!SB || (FAST && SPLIT == 5 && !PRESPLIT), "bf16 storage: the pipelined one-product kernel");
+    constexpr int ES = SB ? 2 : 4;   // bytes per activation element in HBM
     constexpr int NPIECE = SPLIT == 3 ? 3 : (SPLIT == 5 ? 1 : 2);  // 16-bit images per operand
     constexpr int A_BYTES = SPLIT ? NPIECE * BM * LDB * 2 : BM * LDK * 4;
     constexpr int B_BYTES = SPLIT ? NPIECE * BN * LDB * 2 : BN * LDK * 4;
@@ -263,7 +269,11 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         }
     };
 
-    f32x4 ra[4], rb[BROWS];
+    // A rows on their way to LDS: 4 fp32 values, or (SB) 4 bf16 values as two dwords.  (Integer-typed on purpose: carried
+    // in float lanes and bit-cast back element by element, hipcc 7.2 narrows the 8-byte buffer load to 4 bytes.)
+    using AReg = typename std::conditional<SB, u32x2, f32x4>::type;
+    AReg ra[4];
+    f32x4 rb[BROWS];
 
     // ---- FAST loader state
     __amdgpu_buffer_rsrc_t rs_a, rs_b;
@@ -274,8 +284,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         const int ow_ = DGRAD ? g.OWc : g.OW, oh_ = DGRAD ? g.OHc : g.OH;
         const int64_t img0 = (unsigned)m0 / (unsigned)(oh_ * ow_);
         const int64_t ipix = (int64_t)g.IH * g.IW;
-        const int64_t bytes = ((((int64_t)g.nimg - img0) * ipix - 1) * g.ldi + g.IC) * 4;
-        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + img0 * ipix * g.ldi), 0,
+        const int64_t bytes = ((((int64_t)g.nimg - img0) * ipix - 1) * g.ldi + g.IC) * ES;
+        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(in) + img0 * ipix * g.ldi * ES), 0,
                                                  bytes > 0xffffffffLL ? (int)0xffffffffu : (int)(unsigned)bytes,
                                                  0x00020000);
         rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, g.OC * g.KtotFull * 4, 0x00020000);
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int relpix = (a_base[j] - (int)(img0 * ipix)) + a_y0[j] * g.IW + a_x0[j];
-            a_rel[j] = (relpix * (int)g.ldi + kq) * 4;
+            a_rel[j] = (relpix * (int)g.ldi + kq) * ES;
             // bit (th * ntw + tw) = tap inside the image: row validity x column validity, branch-free (the taps of a
             // FAST launch are at most 5 x 5: ntaps <= 31)
             const int nth = DGRAD ? g.nkh : g.KH;
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
     const unsigned fast_tw_n = DGRAD ? g.nkw : g.KW;
     const unsigned fast_tw_one = fast_tw_n == 1 ? 1u : 0u;  // magic_u32(1) is 0: q = umulhi(n, 0) + n
     // which = 1: the A rows, 2: the B rows, 3: both
-    auto load_tiles_fast = [&](int k0n, f32x4 (&ra)[4], f32x4 (&rb)[BROWS], int which = 3) {  // k0n is block-uniform: everything up to the per-row adds is scalar
+    auto load_tiles_fast = [&](int k0n, AReg (&ra)[4], f32x4 (&rb)[BROWS], int which = 3) {  // k0n is block-uniform: everything up to the per-row adds is scalar
         const bool kin = k0n < g.Ktot;
         const int tap = (int)__umulhi((unsigned)k0n, g.magic_ic);  // IC >= 32 here
         const int c0 = k0n - tap * g.IC;
@@ -317,10 +327,10 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         const int tw = tap - th * (int)fast_tw_n;
         int toff, wcol0;
         if (!DGRAD) {
-            toff = ((th * g.IW + tw) * (int)g.ldi + c0) * 4;
+            toff = ((th * g.IW + tw) * (int)g.ldi + c0) * ES;
             wcol0 = k0n;
         } else {
-            toff = (c0 - (th * g.IW + tw) * (int)g.ldi) * 4;
+            toff = (c0 - (th * g.IW + tw) * (int)g.ldi) * ES;
             wcol0 = ((g.kh0 + g.stride * th) * g.KW + (g.kw0 + g.stride * tw)) * g.IC + c0;
         }
         const int tbit = kin ? tap : 31;  // bit 31 is never set: a prefetch past the last k-step loads zeros
@@ -328,7 +338,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int voff = ((a_mask[j] >> tbit) & 1u) ? a_rel[j] + toff : -1;
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
+                if constexpr (SB) ra[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_a, voff, 0, 0));
+                else ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, 0, 0));
             }
         }
         if (which & 2) {
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
             load_tiles_fast(k0, ra, rb);
             return;
         }
+        if constexpr (!SB) {   // (the generic loaders hold fp32 rows; SB kernels are FAST by construction)
         const int kk = k0 + kq;
         if (VEC) {
             // Branch-free: every lane always loads from a clamped (valid) address and masks the value afterwards,
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
                 }
             }
         }
+        }
     };
     auto split_store = [&](const f32x4& v, __bf16* hi_img, __bf16* mid_img, __bf16* lo_img, int row) {
         bf16x4 hi, mid, lo;
@@ -415,7 +428,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         *reinterpret_cast<bf16x4*>(&lo_img[row * LDB + kq]) = lo;
     };
     auto store_tiles = [&]() {
-        if (SPLIT) {
+        if constexpr (SB) return;
+        else if (SPLIT) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) split_store(ra[j], Ah, Am, Al, lr + 32 * j);
 #pragma unroll
@@ -486,6 +500,10 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
                 p = __builtin_convertvector(rest, bf16x2);
                 out[1][e] = p[0]; out[1][e + 1] = p[1];
             }
+        };
+        auto convert_a = [&](const AReg& v, bf16x4* out) {
+            if constexpr (SB) out[0] = __builtin_bit_cast(bf16x4, v);   // already the bf16 values
+            else convert(v, out, kF16ActScale);
         };
         auto convert_b = [&](const f32x4& v, bf16x4* out) {
             if constexpr (PRESPLIT) {   // the 16 bytes already are (4 hi, 4 lo)
@@ -562,11 +580,12 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         if (g.Ktot > 0) {
             // both first tiles are requested back to back (the accumulators are not live yet, registers are free):
             // one exposed memory latency per block instead of two
-            f32x4 ra0[4], rb0[BROWS];
+            AReg ra0[4];
+            f32x4 rb0[BROWS];
             load_tiles_fast(0, ra0, rb0);
             load_tiles_fast(BK, ra, rb);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) convert(ra0[j], pa[j], kF16ActScale);
+            for (int j = 0; j < 4; ++j) convert_a(ra0[j], pa[j]);
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) convert_b(rb0[j], pb[j]);
             write_tiles();
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
             mfma_group(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) convert(ra[j], pa[j], kF16ActScale);
+            for (int j = 0; j < 4; ++j) convert_a(ra[j], pa[j]);
             // shape the schedule: operand reads, then every MFMA followed by its share of the conversion VALU
             __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
@@ -760,9 +779,13 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
         const int lrow = lane_id / LPR;
         const int c4 = (lane_id % LPR) * 4;
         const int n = n0 + wn * TN * 32 + c4;
-        float* out_g = out + mrow0 * g.ldo;
-        const float* ad1_g = addend ? addend + mrow0 * ld_add : nullptr;
-        const float* ad2_g = addend2 ? addend2 + mrow0 * ld_add2 : nullptr;
+        typedef SnnStore<SB> St;   // fp32 tensors, or bf16 (rounded here) in the bf16-storage mode
+        char* const out_b = reinterpret_cast<char*>(out);
+        const char* const ad1_b = reinterpret_cast<const char*>(addend);
+        const char* const ad2_b = reinterpret_cast<const char*>(addend2);
+        char* out_g = out_b + mrow0 * g.ldo * ES;
+        const char* ad1_g = addend ? ad1_b + mrow0 * ld_add * ES : nullptr;
+        const char* ad2_g = addend2 ? ad2_b + mrow0 * ld_add2 * ES : nullptr;
         const int o_l = lrow * (int)g.ldo + n, a1_l = lrow * (int)ld_add + n, a2_l = lrow * (int)ld_add2 + n;
 #pragma unroll
         for (int pass = 0; pass < 32 / RPP; ++pass) {
@@ -770,34 +793,34 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SN
             const int64_t m = mrow0 + row;
             if (m >= g.Mtot || n >= g.OC) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
-            float* dst;
-            const float *a1p, *a2p;
+            char* dst;
+            const char *a1p, *a2p;
             if (linear) {
-                dst = out_g + (o_l + pass * RPP * (int)g.ldo);
-                a1p = ad1_g + (a1_l + pass * RPP * (int)ld_add);
-                a2p = ad2_g + (a2_l + pass * RPP * (int)ld_add2);
+                dst = out_g + (o_l + pass * RPP * (int)g.ldo) * ES;
+                a1p = ad1_g + (a1_l + pass * RPP * (int)ld_add) * ES;
+                a2p = ad2_g + (a2_l + pass * RPP * (int)ld_add2) * ES;
             } else {
                 const unsigned t = (unsigned)m / (unsigned)g.OWc;
                 const int b = (int)((unsigned)m - t * (unsigned)g.OWc);
                 const unsigned img = t / (unsigned)g.OHc;
                 const int a = (int)(t - img * (unsigned)g.OHc);
                 const int64_t pix = ((int64_t)img * g.OH + (a * g.stride + g.ph)) * g.OW + (b * g.stride + g.pw);
-                dst = out + pix * g.ldo + n;
-                a1p = addend + pix * ld_add + n;
-                a2p = addend2 + pix * ld_add2 + n;
+                dst = out_b + (pix * g.ldo + n) * ES;
+                a1p = ad1_b + (pix * ld_add + n) * ES;
+                a2p = ad2_b + (pix * ld_add2 + n) * ES;
             }
             if (ovec && n + 3 < g.OC) {
-                if (addend) v += *reinterpret_cast<const f32x4*>(a1p);  // fused accumulation
-                if (addend2) v += *reinterpret_cast<const f32x4*>(a2p);
-                *reinterpret_cast<f32x4*>(dst) = v;
+                if (addend) v += St::ld4(a1p, 0);  // fused accumulation
+                if (addend2) v += St::ld4(a2p, 0);
+                St::st4(dst, 0, v);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (n + q < g.OC) {
                         float o = v[q];
-                        if (addend) o += a1p[q];
-                        if (addend2) o += a2p[q];
-                        dst[q] = o;
+                        if (addend) o += St::ld1(a1p, q);
+                        if (addend2) o += St::ld1(a2p, q);
+                        St::st1(dst, q, o);
                     }
             }
         }
@@ -1023,7 +1046,9 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
 //     address arithmetic; dy rows past the split's last pixel fall off the end of the buffer resource;
 //   * tile k+1 is converted to its bf16 pieces in the shadow of tile k's MFMAs and the loads of tile k+2 are
 //     issued before the barrier; between the two barriers only the LDS writes remain.
-template <int TM, int TN, int WM, int WN, int WBK, bool ONE>   // ONE: bf16 x 1 (hi pieces only, one product)
+// SB (ONE only; bf16-storage mode): x and dy are bf16 tensors - 8-byte loads, the 4 x 4 transposition to "4 pixels of a
+// channel" is bit shuffling, nothing is converted.
+template <int TM, int TN, int WM, int WN, int WBK, bool ONE, bool SB = false>   // ONE: bf16 x 1 (hi pieces only, one product)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, WgradGeom g) {
@@ -1033,6 +1058,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     // WBK pixels per LDS stage: 32 for the large tiles; 64 for the small ones, whose 6-MFMA stages were shorter than
     // the memory latency they have to cover (PMC: 58 % of the wave cycles parked in s_waitcnt / barriers)
     static_assert(WBK == 32 || WBK == 64, "stage length");
+    static_assert(!SB || ONE, "bf16 storage: one product");
+    constexpr int ES = SB ? 2 : 4;   // bytes per activation element in HBM
     constexpr int LDW = WBK + 8;      // bf16 row pitch: 80 / 144 bytes, conflict-free ds_read_b128 fragments
     constexpr int NQ = WBK / 4;       // pixel quads per stage
     constexpr int GPP = kThreads / NQ;
@@ -1069,11 +1096,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     const unsigned img_lo = p_lo / opix;
     __amdgpu_buffer_rsrc_t rs_d, rs_x;
     {
-        const int64_t dbytes = p_hi > p_lo ? (((int64_t)(p_hi - p_lo) - 1) * g.lddy + g.Cout) * 4 : 0;
-        rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (int64_t)p_lo * g.lddy), 0, (int)dbytes,
-                                                 0x00020000);
-        const int64_t xbytes = ((((int64_t)g.nimg - img_lo) * ipix - 1) * g.ldx + g.Cin) * 4;
-        rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)img_lo * ipix * g.ldx), 0,
+        const int64_t dbytes = p_hi > p_lo ? (((int64_t)(p_hi - p_lo) - 1) * g.lddy + g.Cout) * ES : 0;
+        rs_d = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(dy) + (int64_t)p_lo * g.lddy * ES), 0, (int)dbytes, 0x00020000);
+        const int64_t xbytes = ((((int64_t)g.nimg - img_lo) * ipix - 1) * g.ldx + g.Cin) * ES;
+        rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(x) + (int64_t)img_lo * ipix * g.ldx * ES), 0,
                                                  xbytes > 0x7fffffffLL ? 0x7fffffff : (xbytes < 0 ? 0 : (int)xbytes), 0x00020000);
     }
 
@@ -1092,7 +1120,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     for (int q = 0; q < DQ; ++q) {
         d_cq[q] = (grp0 + GPP * q) * 4;
         const bool ok = (grp0 + GPP * q) < DG && (co0 + d_cq[q]) < g.Cout;
-        d_off[q] = ok ? ((quad * 4) * (int)g.lddy + co0 + d_cq[q]) * 4 : -1;
+        d_off[q] = ok ? ((quad * 4) * (int)g.lddy + co0 + d_cq[q]) * ES : -1;
     }
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
@@ -1103,7 +1131,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         const int tap = kcc / g.Cin, ci = kcc - tap * g.Cin;
         x_kh[q] = tap / g.KW;
         x_kw[q] = tap - x_kh[q] * g.KW;
-        x_tapoff[q] = ((x_kh[q] * g.W + x_kw[q]) * (int)g.ldx + ci) * 4;
+        x_tapoff[q] = ((x_kh[q] * g.W + x_kw[q]) * (int)g.ldx + ci) * ES;
     }
 
     // ---- pixel decode, 32 lanes, one stage ahead (carries instead of divisions inside the loop)
@@ -1121,7 +1149,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         if (tid < WBK) {
             const int y0 = d_oy * g.stride - g.pad, x0 = d_ox * g.stride - g.pad;
             int4 info;
-            info.x = ((d_img * (int)ipix + y0 * g.W + x0) * (int)g.ldx) * 4;
+            info.x = ((d_img * (int)ipix + y0 * g.W + x0) * (int)g.ldx) * ES;
             info.y = y0;
             info.z = x0;
             info.w = d_p < p_hi ? 1 : 0;
@@ -1138,29 +1166,45 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         }
     };
 
-    f32x4 rd[DQ][4], rx[XQ][4];
+    // operand quads on their way to LDS: 4 fp32 values, or (SB) 4 bf16 values as two dwords (integer-typed: see k_conv_gather)
+    using OReg = typename std::conditional<SB, u32x2, f32x4>::type;
+    OReg rd[DQ][4], rx[XQ][4];
     auto load_tiles = [&](unsigned p0, int slot) {
-        const int dstage = (int)(p0 - p_lo) * (int)g.lddy * 4;  // scalar
+        const int dstage = (int)(p0 - p_lo) * (int)g.lddy * ES;  // scalar
+        auto fetch = [&](__amdgpu_buffer_rsrc_t rs, int voff) -> OReg {
+            if constexpr (SB) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+            else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+        };
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int4 info = *reinterpret_cast<const int4*>(&Pinfo[slot][quad * 4 + e][0]);
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
-                const int voff = d_off[q] < 0 ? -1 : d_off[q] + e * (int)g.lddy * 4 + dstage;
-                rd[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, voff, 0, 0));
+                const int voff = d_off[q] < 0 ? -1 : d_off[q] + e * (int)g.lddy * ES + dstage;
+                rd[q][e] = fetch(rs_d, voff);
             }
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
                 const int iy = info.y + x_kh[q], ix = info.z + x_kw[q];
                 const bool ok = (info.w != 0) & x_ok[q] & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
                 const int voff = ok ? info.x + x_tapoff[q] : -1;
-                rx[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, 0, 0));
+                rx[q][e] = fetch(rs_x, voff);
             }
         }
     };
     // 4 pixels x 4 channels -> per channel the 4 pixels as bf16 hi / lo (8 bytes each), kept in registers
     bf16x4 pd[DQ][4][2], px[XQ][4][2];
-    auto convert_quad = [&](const f32x4 (&v)[4], bf16x4 (&out)[4][2]) {
+    auto convert_quad = [&](const OReg (&v)[4], bf16x4 (&out)[4][2]) {
+        if constexpr (SB) {   // v[pixel] holds channels (0, 1) in element 0 and (2, 3) in element 1, as bf16 pairs
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned a0 = v[0][c >> 1], a1 = v[1][c >> 1], a2 = v[2][c >> 1], a3 = v[3][c >> 1];
+                u32x2 o;
+                if (c & 1) o = u32x2{(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+                else o = u32x2{(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
+                out[c][0] = __builtin_bit_cast(bf16x4, o);
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1176,6 +1220,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
                     out[c][1][e] = pp[0]; out[c][1][e + 1] = pp[1];
                 }
             }
+        }
     };
     auto write_tiles = [&]() {
 #pragma unroll
@@ -1233,7 +1278,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     };
     constexpr int NM = TM * TN * (ONE ? 1 : 3);
     constexpr int NREAD = (TM + TN) * (ONE ? 1 : 2);
-    constexpr int VPG_D = (DQ * 56 + NM - 1) / NM, VPG_X = (XQ * 56 + NM - 1) / NM;
+    constexpr int CQ_OPS = SB ? 12 : 56;   // VALU per converted quad (approx.)
+    constexpr int VPG_D = (DQ * CQ_OPS + NM - 1) / NM, VPG_X = (XQ * CQ_OPS + NM - 1) / NM;
 
     decode(0);
     __syncthreads();
@@ -1363,11 +1409,13 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_reduce4(const float* __restr
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DGRAD, int SPLIT>
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+template <bool DGRAD, int SPLIT, bool SB = false>
 static int launch_gather(const float* in, const float* wk, const void* wk_split, float* out, const ConvGeom& g,
                          const float* addend, int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st,
                          const char* name) {
-    const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && aligned16(in) && aligned16(wk);
+    const bool vec = (g.IC % 4 == 0) && (g.ldi % 4 == 0) && (SB ? aligned8(in) : aligned16(in)) && aligned16(wk);
     const int64_t gm = snn_ceil_div(g.Mtot, BM);
     SNN_REQUIRE(g.Mtot < 0x7fffffffLL && (int64_t)g.IH * g.IW < 0x7fffffffLL, "%s: too many pixels", name);
     const int ntaps = DGRAD ? g.nkh * g.nkw : g.KH * g.KW;
@@ -1376,8 +1424,12 @@ static int launch_gather(const float* in, const float* wk, const void* wk_split,
                       (DGRAD ? g.nkh : g.KH) <= 6 && (DGRAD ? g.nkw : g.KW) <= 6 &&
                       (int64_t)g.IH * g.IW * g.ldi * 16 < 0x7fffffffLL && (int64_t)g.OC * g.KtotFull * 4 < 0x7fffffffLL;
     ConvGeom gg = g;
-    gg.out_vec = (g.ldo % 4 == 0) && aligned16(out) && (!addend || (ld_add % 4 == 0 && aligned16(addend))) &&
-                 (!addend2 || (ld_add2 % 4 == 0 && aligned16(addend2)));
+    const auto avec = [](const void* p) { return SB ? aligned8(p) : aligned16(p); };   // 4 elements per access
+    gg.out_vec = (g.ldo % 4 == 0) && avec(out) && (!addend || (ld_add % 4 == 0 && avec(addend))) &&
+                 (!addend2 || (ld_add2 % 4 == 0 && avec(addend2)));
+    if constexpr (SB)
+        SNN_REQUIRE(fast, "%s: bf16 storage covers the pipelined implicit GEMM only (channels a multiple of 32, pixel "
+                    "stride a multiple of 4, 8-byte aligned tensors): %d channels, stride %lld", name, g.IC, (long long)g.ldi);
     // the pre-split weight image serves the pipelined kernel in its two-piece modes; every other path converts wk itself
     const bool presplit = wk_split != nullptr && (SPLIT == 2 || SPLIT == 4) && aligned16(wk_split);
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
@@ -1387,7 +1439,10 @@ static int launch_gather(const float* in, const float* wk, const void* wk_split,
         gg.ntiles = (int)snn_ceil_div(g.OC, BN_);                                                           \
         SNN_REQUIRE((int64_t)gg.mtiles_per_xcd * 8 * gg.ntiles <= 0x7fffffffLL, "%s: grid too large", name); \
         dim3 grid((unsigned)(gg.mtiles_per_xcd * 8 * gg.ntiles));                                           \
-        if (fast && presplit) {                                                                             \
+        if constexpr (SB) {                                                                                 \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, 5, true, false, true>), grid,     \
+                               dim3(kThreads), 0, st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);   \
+        } else if (fast && presplit) {                                                                      \
             if constexpr (SPLIT == 2 || SPLIT == 4)                                                         \
                 hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, SPLIT, true, true>), grid,    \
                                    dim3(kThreads), 0, st, in, static_cast<const float*>(wk_split), out, gg, addend, \
@@ -1888,11 +1943,14 @@ struct FirstGeom {
 
 // One block walks output ROWS (block-uniform row index: the image / row split and the vertical bounds are scalar
 // work), its PP pixel lanes walk the row; per pixel all nine input positions are loaded before any is tested.
-template <int CIN, int KS, bool WGRAD, bool BNAPPLY = false>
+// SB (bf16-storage mode): the wide tensors - y (forward), dy / gx and the saved y (weight gradient) - are bf16; the event
+// frames x stay fp32.
+template <int CIN, int KS, bool WGRAD, bool BNAPPLY = false, bool SB = false>
 __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          FirstGeom g) {
     static_assert(CIN == 2, "float2 input pixels");
+    typedef SnnStore<SB> St;
     constexpr int KT = KS * KS * CIN;
     __shared__ float red[WGRAD ? kThreads : 1][KT + 1];
     __shared__ double sred[WGRAD ? 1 : kThreads][9];               // statistics of the forward pass (8 used: odd pitch)
@@ -1939,12 +1997,11 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
                 srow[kh * LW + ixp] = ok ? t : make_float2(0.f, 0.f);
             }
         __syncthreads();
-        const float* dyrow = WGRAD ? dy + (int64_t)r * g.Wo * g.ldy + cg * 4 : nullptr;
-        float* yrow = WGRAD ? nullptr : out + (int64_t)r * g.Wo * g.ldy + cg * 4;
-        const float* byrow = nullptr;
+        const int64_t dyrow = (int64_t)r * g.Wo * g.ldy + cg * 4;   // element index of the row's first pixel in dy / out
+        int64_t byrow = 0;
         f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca, cc = ca;
         if constexpr (WGRAD && BNAPPLY) {   // the row's timestep is block-uniform: three coefficient quads per row
-            byrow = g.bn_y + (int64_t)r * g.Wo * g.bn_ldy + cg * 4;
+            byrow = (int64_t)r * g.Wo * g.bn_ldy + cg * 4;
             const float* cf = g.bn_coef + (int64_t)(img / g.bn_fps) * g.Cout + cg * 4;
             ca = *reinterpret_cast<const f32x4*>(cf);
             cb = *reinterpret_cast<const f32x4*>(cf + g.bn_tc);
@@ -1958,9 +2015,9 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
 #pragma unroll
                 for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow[kh * LW + ox * g.stride + kw];
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (WGRAD) gv = *reinterpret_cast<const f32x4*>(dyrow + ox * ldy);
+            if (WGRAD) gv = St::ld4(dy, dyrow + ox * ldy);
             if constexpr (WGRAD && BNAPPLY) {   // the statement of k_bn_bwd_apply (neuron.hip): same roundings
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(byrow + ox * (int)g.bn_ldy);
+                const f32x4 yv = St::ld4(g.bn_y, byrow + ox * (int)g.bn_ldy);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) gv[c] = ca[c] * gv[c] + cb[c] * yv[c] + cc[c];
             }
@@ -1984,7 +2041,7 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
                 }
             if (!WGRAD) {
                 f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
-                *reinterpret_cast<f32x4*>(yrow + ox * ldy) = o;
+                St::st4(out, dyrow + ox * ldy, o);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     row_s[c] += acc[c];
@@ -2034,8 +2091,6 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
         }
     }
 }
-
-static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 // the shapes the two kernels above take: the caller checks alignment of its buffers on top
 static bool first_layer_shape(int Cin, int Cout, int KH, int KW) {
@@ -2141,8 +2196,9 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
     SNN_REQUIRE(!w_split || precision == SNN_PREC_FP16X3,
                 "snn_conv2d_fwd: a pre-split weight image exists for SNN_PREC_FP16X3 only (precision %d)", precision);
     SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X6 || precision == SNN_PREC_FP16X3 ||
-                    precision == SNN_PREC_BF16X1,
-                "snn_conv2d_fwd: precision must be SNN_PREC_FP32, _BF16X6, _FP16X3 or _BF16X1 (got %d)", precision);
+                    precision == SNN_PREC_BF16X1 || precision == SNN_PREC_BF16S,
+                "snn_conv2d_fwd: precision must be SNN_PREC_FP32, _BF16X6, _FP16X3, _BF16X1 or _BF16S (got %d)", precision);
+    const bool sbf = precision == SNN_PREC_BF16S;   // x (but for the fp32 event frames), y, addend are bf16
     const int fwd_split = precision;
     if (check_conv_shape("snn_conv2d_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout, "snn_conv2d_fwd: pixel stride smaller than channel count");
@@ -2166,7 +2222,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
-    if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 && aligned16(y) &&
+    if (first_layer_shape(Cin, Cout, KH, KW) && !addend && ldx % 2 == 0 && aligned8(x) && ldy % 4 == 0 &&
+        (sbf ? aligned8(y) : aligned16(y)) &&
         (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
         FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), 0, nullptr,
@@ -2182,12 +2239,18 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
             blocks = steps * fgr.blocks;
             bn_layout[0] = fgr.blocks;
         }
-        hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
-                           (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
+        if (sbf)
+            hipLaunchKernelGGL((k_conv_first<2, 3, false, false, true>), dim3((unsigned)blocks), dim3(kThreads),
+                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
+        else
+            hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
+                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_fwd");
         return 0;
     }
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+    SNN_REQUIRE(!sbf || Cin % 32 == 0, "snn_conv2d_fwd: bf16 storage covers the event-frame layer (fp32 frames, Cin = 2, "
+                "3x3) and layers with a multiple of 32 input channels (got %d)", Cin);
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && !sbf) {
         const int64_t chunks = bn_partial ? direct_bn_chunks(frames_per_step, Ho, Wo) : 0;
         const int rc = launch_direct3<false>(x, ldx, w, y, ldy, N, H, W, Cin, Cout, fwd_split, addend, ld_addend,
                                              nullptr, 0, chunks <= 0x7fffffff ? bn_partial : nullptr, (int)chunks,
@@ -2204,6 +2267,8 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
         bn_layout[0] = g.bn_chunks;
         bn_layout[1] = BM;
     }
+    if (sbf)
+        return launch_gather<false, 5, true>(x, w, nullptr, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 5)
         return launch_gather<false, 5>(x, w, nullptr, y, g, addend, ld_addend, nullptr, 0, (hipStream_t)stream, "snn_conv2d_fwd");
     if (fwd_split == 4)
@@ -2220,8 +2285,10 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     SNN_REQUIRE(dy && wt && dx, "snn_conv2d_dgrad: null pointer");
     SNN_REQUIRE(!wt_split || precision == SNN_PREC_BF16X3,
                 "snn_conv2d_dgrad: a pre-split weight image exists for SNN_PREC_BF16X3 only (precision %d)", precision);
-    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1,
-                "snn_conv2d_dgrad: precision must be SNN_PREC_FP32, SNN_PREC_BF16X3 or SNN_PREC_BF16X1 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1 ||
+                    precision == SNN_PREC_BF16S,
+                "snn_conv2d_dgrad: precision must be SNN_PREC_FP32, _BF16X3, _BF16X1 or _BF16S (got %d)", precision);
+    const bool sbf = precision == SNN_PREC_BF16S;   // dy, dx and the addends are bf16
     const int bwd_split = precision;
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv2d_dgrad: addend2 pixel stride smaller than channel count");
     if (check_conv_shape("snn_conv2d_dgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
@@ -2238,7 +2305,7 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
     SNN_REQUIRE(N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)g.KtotFull * Cout < 0xffffffffLL,
                 "snn_conv2d_dgrad: tensor too large for 32-bit pixel indexing");
     const bool split = bwd_split != 0;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && bwd_split != SNN_PREC_BF16X1) {  // dx = conv(dy, mirrored taps of w^T)
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && bwd_split != SNN_PREC_BF16X1 && !sbf) {  // dx = conv(dy, mirrored taps of w^T)
         const int rc = launch_direct3<true>(dy, lddy, wt, dx, lddx, N, H, W, Cout, Cin, split ? 2 : 0, addend,
                                             ld_addend, addend2, ld_addend2, nullptr, 0, (hipStream_t)stream,
                                             "snn_conv2d_dgrad");
@@ -2256,7 +2323,9 @@ extern "C" int snn_conv2d_dgrad(const float* dy, int64_t lddy, const float* wt, 
             g.Mtot = N * g.OHc * (int64_t)g.OWc;
             g.Ktot = g.nkh * g.nkw * Cout;
             g.magic_ic = magic_u32(Cout); g.magic_kw = magic_u32(g.nkw);
-            int rc = bwd_split == SNN_PREC_BF16X1
+            int rc = sbf ? launch_gather<true, 5, true>(dy, wt, nullptr, dx, g, addend, ld_addend, addend2, ld_addend2,
+                                                        (hipStream_t)stream, "snn_conv2d_dgrad")
+                     : bwd_split == SNN_PREC_BF16X1
                          ? launch_gather<true, 5>(dy, wt, nullptr, dx, g, addend, ld_addend, addend2, ld_addend2,
                                                   (hipStream_t)stream, "snn_conv2d_dgrad")
                          : (split ? launch_gather<true, 2>(dy, wt, wt_split, dx, g, addend, ld_addend, addend2, ld_addend2,
@@ -2302,7 +2371,7 @@ static WgradTile wgrad_tile(int Cout, int Ktot, bool split, int64_t M) {
 extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                                        int stride, int pad, int precision) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 1;
-    const int bwd_split = precision == SNN_PREC_FP32 ? 0 : 1;
+    const int bwd_split = precision == SNN_PREC_FP32 ? 0 : 1;   // SNN_PREC_BF16S plans like the other 16-bit modes
     if (bwd_split) {  // 3x3 layers with whole 32-channel tiles: the halo-resident kernel (wgrad_halo.hip)
         const SnnWgradHaloPlan hp = snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad);
         if (hp.ok) return hp.slabs;
@@ -2372,8 +2441,9 @@ static int wgrad_reduce_slabs(float* workspace, float* dw, int64_t n, int splitk
 
 namespace {
 static bool first_layer_wgrad_ok(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t N, int H, int W, int Cin,
-                                 int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad) {
-    return first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 && aligned16(dy) &&
+                                 int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, bool dy_bf16 = false) {
+    return first_layer_shape(Cin, Cout, KH, KW) && ldx % 2 == 0 && aligned8(x) && lddy % 4 == 0 &&
+           (dy_bf16 ? aligned8(dy) : aligned16(dy)) &&
            (int64_t)W * ldx < 0x7fffffffLL && N * Ho < 0x7fffffffLL && W + 2 * pad <= 1408 &&
            (Wo - 1) * stride + 3 <= W + 2 * pad;
 }
@@ -2411,9 +2481,11 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
                                 int accumulate, float* workspace, int splitk, int precision, void* stream) {
     SNN_REQUIRE(x && dy && dw && workspace, "snn_conv2d_wgrad: null pointer");
-    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1,
-                "snn_conv2d_wgrad: precision must be SNN_PREC_FP32, SNN_PREC_BF16X3 or SNN_PREC_BF16X1 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1 ||
+                    precision == SNN_PREC_BF16S,
+                "snn_conv2d_wgrad: precision must be SNN_PREC_FP32, _BF16X3, _BF16X1 or _BF16S (got %d)", precision);
     const int bwd_split = precision;
+    const bool sbf = precision == SNN_PREC_BF16S;   // x (but for the fp32 event frames) and dy are bf16
     if (check_conv_shape("snn_conv2d_wgrad", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
     SNN_REQUIRE(ldx >= Cin && lddy >= Cout, "snn_conv2d_wgrad: pixel stride smaller than channel count");
     SNN_REQUIRE(splitk >= 1 && splitk <= 32768, "snn_conv2d_wgrad: bad splitk %d", splitk);
@@ -2424,11 +2496,15 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
-    if (first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) {
+    if (first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, sbf)) {
         FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
                         nullptr, 0, nullptr, 0, 1};
-        hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
-                           (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
+        if (sbf)
+            hipLaunchKernelGGL((k_conv_first<2, 3, true, false, true>), dim3((unsigned)splitk), dim3(kThreads),
+                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
+        else
+            hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
+                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
         return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
     }
@@ -2438,7 +2514,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
             SNN_REQUIRE(splitk == hp.slabs, "snn_conv2d_wgrad: splitk %d, expected %d (snn_conv2d_wgrad_splitk)", splitk,
                         hp.slabs);
             const int rc = snn_wgrad_halo_launch(hp, x, ldx, dy, lddy, workspace, N, H, W, Cin, Ho, Wo, Cout, stride,
-                                                 precision == SNN_PREC_BF16X1 ? 1 : 3, (hipStream_t)stream);
+                                                 (precision == SNN_PREC_BF16X1 || sbf) ? 1 : 3, sbf, (hipStream_t)stream);
             if (rc == 0)
                 return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, hp.slabs, accumulate,
                                           (hipStream_t)stream);
@@ -2446,8 +2522,8 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
             // rc < 0: buffers this kernel cannot address (unaligned / > 2 GiB per image): the implicit-GEMM kernel
         }
     }
-    const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && aligned16(x) &&
-                     aligned16(dy);
+    const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) &&
+                     (sbf ? aligned8(x) && aligned8(dy) : aligned16(x) && aligned16(dy));
     const WgradTile t = wgrad_tile(Cout, g.Ktot, bwd_split && Cin % 4 == 0 && Cout % 4 == 0, g.Mtot);
     // small tiles (64 x 64, 32 x 128) run 64-pixel stages in the pipelined kernel (latency cover), the others 32
     static const int wbk_small = snn_tuning_env("SNN_WGRAD_WBK") ? atoi(snn_tuning_env("SNN_WGRAD_WBK")) : 64;  // tuning aid
@@ -2459,7 +2535,9 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     static const bool no_pipe = snn_tuning_env("SNN_WGRAD_NO_PIPE") != nullptr;  // tuning / bisecting aid
     const bool pipe = vec && bwd_split && !no_pipe && g.Mtot < 0x7fffffffLL && span_pix * ldx * 4 < 0x7fffffffLL &&
                       g.pix_per_split * lddy * 4 < 0x7fffffffLL && (int64_t)H * W * ldx * 4 < 0x7fffffffLL;
-    const bool one = precision == SNN_PREC_BF16X1;
+    const bool one = precision == SNN_PREC_BF16X1 || sbf;
+    SNN_REQUIRE(!sbf || pipe, "snn_conv2d_wgrad: bf16 storage covers the event-frame layer and the pipelined kernels only "
+                "(channels and strides multiples of 4, 8-byte aligned tensors, < 2 GiB per pixel split)");
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
     g.splitk = splitk;
@@ -2469,7 +2547,13 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (pipe && one && wbk == 64)                                                                          \
+        if (sbf && wbk == 64)                                                                                  \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, true, true>), grid, dim3(kThreads), 0, st, x, dy, \
+                               workspace, g);                                                                  \
+        else if (sbf)                                                                                          \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32, true, true>), grid, dim3(kThreads), 0, st, x, dy, \
+                               workspace, g);                                                                  \
+        else if (pipe && one && wbk == 64)                                                                     \
             hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, true>), grid, dim3(kThreads), 0, st, x, dy, \
                                workspace, g);                                                                  \
         else if (pipe && one)                                                                                  \

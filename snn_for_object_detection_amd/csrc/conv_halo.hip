@@ -28,6 +28,7 @@
 // Epilogue as in k_conv_gather: accumulators transposed through LDS, 16-byte stores, up to two fused addends
 // (gradient accumulation), BatchNorm statistics partials of the stored values (forward).
 #include <stdlib.h>
+#include <type_traits>
 #include "snn_common.h"
 
 namespace {
@@ -113,7 +114,11 @@ constexpr int BN_CMAX = 128;  // input channels (K) the BNAP variant supports
 // (kh-1)*34 + (kw-1).  Everything else - chunk staging, weight DMA, epilogue - is the strip kernel's.
 constexpr int RTH = 4, RTW = 32, RPITCH = RTW + 2, RCELLS = (RTH + 2) * RPITCH;
 
-template <int CO, bool F16, int ABL = 0, bool BNAP = false, bool RECT = false>
+// SBF (SNN_PREC_BF16S, the bf16-STORAGE throughput mode): x, y and the addends are bf16 tensors.  The staged halo is then
+// the bf16 image itself (8-byte loads, no split: ONE piece), the weight image's high pieces are the bf16-rounded weights
+// (the low pieces are neither copied nor multiplied): one MFMA product per multiply-add; results are rounded to bf16 in
+// the epilogue (the BatchNorm partials are taken from the fp32 values before that rounding).
+template <int CO, bool F16, int ABL = 0, bool BNAP = false, bool RECT = false, bool SBF = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
                                                            const unsigned char* __restrict__ wimg,
                                                            float* __restrict__ y, HaloGeom g,
@@ -125,6 +130,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     constexpr int WM = 2, WN = 2, TM = 2, TN = CO / 64;
     constexpr int BTILE = (CO / 32) * 4096;     // bytes of one k-step's weight tile
     constexpr int NDMA = (CO / 32) * 4 / 4;     // 1-KiB LDS-DMA pieces per wave and k-step
+    constexpr int ES = SBF ? 2 : 4;             // bytes per activation element in HBM
+    static_assert(!SBF || (!F16 && !BNAP && ABL == 0), "bf16 storage: bf16 MFMA, plain variant");
     constexpr int CF_BYTES = BNAP ? 3 * BN_NT * BN_CMAX * 4 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE + CF_BYTES];   // ONE array
     unsigned char* Aimg = smem;                        // [2 pieces][HCELLS][64 B]
@@ -168,9 +175,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     // ---- halo loader: thread (cell = pass * 32 + tid / 8, channel quad = tid % 8)
     const int quad = tid & 7;
     const int64_t ipix = (int64_t)g.H * g.W;
-    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * 4;
+    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * ES;
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (int64_t)nb * ipix * g.ldx), 0, xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+        reinterpret_cast<char*>(const_cast<float*>(x)) + (int64_t)nb * ipix * g.ldx * ES, 0,
+        xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_y = rs_x, rs_dy = rs_x;
     [[maybe_unused]] const int t_lo = BNAP ? nb / g.bn_fps : 0;
     [[maybe_unused]] int cofs[NPASS];      // BNAP: float offset of (timestep of the cell, channel quad) inside a coefficient plane
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             ok = n >= 0 && n < g.N && xx < g.W && yy < g.H;
         }
         const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
-        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;   // >= 2 GiB: range check -> zeros
+        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * ES) : 0x80000000u;   // >= 2 GiB: range check -> zeros
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
         if constexpr (BNAP) {
             int ts = ok ? n / g.bn_fps - t_lo : 0;
@@ -249,6 +257,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     // (the vmcnt of the k-step's closing statement).  M0 (the LDS destination) is written in the statement that uses it.
     const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bimg;
     auto dma_b = [&](int kk, int buf) {   // kk = chunk * 9 + tap
+        if constexpr (SBF)
+            if (wave & 1) return;   // pieces wave, wave + 4, ...: the odd waves hold the LOW pieces, unused with one product
         const int chunk = kk / 9, tap = kk - chunk * 9;
         const unsigned char* src = wsrc + ((int64_t)(tap * nchunks + chunk) * co_tiles) * 4096 + wave * 1024;
         const unsigned dst = lds_b + buf * BTILE + wave * 1024;
@@ -262,15 +272,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
         }
     };
 
-    f32x4 pf[NPASS];
+    // a staging pass on its way to LDS: 4 fp32 values, or (SBF) 4 bf16 values as two dwords.  (Integer-typed on purpose:
+    // carried in float lanes and bit-cast back element by element, hipcc 7.2 narrows the 8-byte buffer load to 4 bytes.)
+    using PReg = typename std::conditional<SBF, u32x2, f32x4>::type;
+    PReg pf[NPASS];
     auto store_halo = [&]() {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            u32x2 hi, lo;
-            split4<F16>(pf[p], hi, lo);
-            *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
-            *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+            if constexpr (SBF) {
+                *reinterpret_cast<u32x2*>(Aimg + awr[p]) = pf[p];
+            } else {
+                u32x2 hi, lo;
+                split4<F16>(pf[p], hi, lo);
+                *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
+                *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+            }
         }
+    };
+    auto load_pass = [&](int off) -> PReg {   // one staging pass: 4 channels of one halo cell
+        if constexpr (SBF) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0));
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     };
 
     // BNAP: gx -> dy for one landed pass (the statement of k_bn_bwd_apply, same roundings) and the store of the tile's own cells
@@ -309,19 +330,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                     continue;
                 }
                 ah[i] = *reinterpret_cast<const bf16x8*>(Aimg + off);
-                al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
+                if constexpr (!SBF) al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int off = (wn * TN + j) * 4096 + ks * 2048 + lane * 16;
                 bh[j] = *reinterpret_cast<const bf16x8*>(Bb + off);
-                bl[j] = *reinterpret_cast<const bf16x8*>(Bb + off + 1024);
+                if constexpr (!SBF) bl[j] = *reinterpret_cast<const bf16x8*>(Bb + off + 1024);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {   // small terms first
-                    if constexpr (F16) {
+                    if constexpr (SBF) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    } else if constexpr (F16) {
                         const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]), xal = __builtin_bit_cast(f16x8, al[i]);
                         const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal, xbh, acc[i][j], 0, 0, 0);
@@ -339,8 +362,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     // ---- prologue: halo of chunk 0 and the first weight tile
     dma_b(0, 0);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-        pf[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[p], 0, 0));
+    for (int p = 0; p < NPASS; ++p) pf[p] = load_pass((int)voff[p]);
     if constexpr (BNAP) {
         f32x4 py[NPASS];
 #pragma unroll
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 #pragma unroll 1
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
-        const int cbytes = (chunk + 1) * 128;   // channel offset of the NEXT chunk
+        const int cbytes = (chunk + 1) * 32 * ES;   // channel offset of the NEXT chunk
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kk = chunk * 9 + tap;
@@ -368,9 +390,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
             // one staging pass of the next chunk's halo per tap: it is YOUNGER than this step's LDS-DMA, so the
             // counted wait below leaves it in flight for a whole k-step (out-of-range offsets when there is no next chunk)
-            if constexpr (!(ABL & 4))
-                pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            if constexpr (!(ABL & 4)) pf[tap] = load_pass(more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u);
             if constexpr (BNAP)
                 pfy[tap & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                               rs_y, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     const int nch = n0c + wn * TN * 32 + c4;
     const int cells_left = g.group_cells - c0;     // cells of the group from the tile start on
     double ssum[4] = {0.0, 0.0, 0.0, 0.0}, qsum[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool stats = F16 && g.bn_partial != nullptr;
+    const bool stats = (F16 || SBF) && g.bn_partial != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -448,18 +468,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                 continue;
             }
             const int64_t pix = ((int64_t)n * g.H + yy) * g.W + xx;
-            float* dst = y + pix * g.ldy + nch;
+            typedef SnnStore<SBF> St;   // fp32 tensors, or bf16 (rounded here) in the bf16-storage mode
             if (ovec) {
-                if (addend) val += *reinterpret_cast<const f32x4*>(addend + pix * g.ld_add + nch);   // fused accumulation
-                if (addend2) val += *reinterpret_cast<const f32x4*>(addend2 + pix * g.ld_add2 + nch);
-                *reinterpret_cast<f32x4*>(dst) = val;
+                if (addend) val += St::ld4(addend, pix * g.ld_add + nch);   // fused accumulation
+                if (addend2) val += St::ld4(addend2, pix * g.ld_add2 + nch);
+                St::st4(y, pix * g.ldy + nch, val);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float o = val[q];
-                    if (addend) o += addend[pix * g.ld_add + nch + q];
-                    if (addend2) o += addend2[pix * g.ld_add2 + nch + q];
-                    dst[q] = o;
+                    if (addend) o += St::ld1(addend, pix * g.ld_add + nch + q);
+                    if (addend2) o += St::ld1(addend2, pix * g.ld_add2 + nch + q);
+                    St::st1(y, pix * g.ldy + nch + q, o);
                 }
             }
             if (stats) {
@@ -523,12 +543,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 // their class: kh = 1 -> even rows from dy row a; kh = 0 -> odd rows from dy row a + 1; kh = 2 -> odd rows from dy row a
 // (columns alike).  Four accumulator sets of 32 cells x 64 channels per wave (128 registers), 4 waves over the cells,
 // 64 dx channels per block.  The weight image is the stride-1 data-gradient image (mirrored taps): tap t is read at 8 - t.
+template <bool SBF = false>   // SBF: dy, dx and the addends are bf16 tensors, one product (see k_conv_halo3)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __restrict__ x,   // dy
                                                               const unsigned char* __restrict__ wimg,
                                                               float* __restrict__ y,         // dx
                                                               HaloGeom g, const float* __restrict__ addend,
                                                               const float* __restrict__ addend2) {
     constexpr int CO = 64, TN = 2;
+    constexpr int ES = SBF ? 2 : 4;
     constexpr int BTILE = (CO / 32) * 4096;
     constexpr int NDMA = (CO / 32) * 4 / 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE];
@@ -550,9 +572,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
 
     const int quad = tid & 7;
     const int64_t ipix = (int64_t)g.H * g.W;
-    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * 4;
+    const int64_t xbytes = ((((int64_t)g.N - nb) * ipix - 1) * g.ldx + g.Cin) * ES;
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (int64_t)nb * ipix * g.ldx), 0, xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
+        reinterpret_cast<char*>(const_cast<float*>(x)) + (int64_t)nb * ipix * g.ldx * ES, 0,
+        xbytes > 0x7fffffffLL ? 0x7fffffff : (int)xbytes, 0x00020000);
     unsigned voff[NPASS];
     int awr[NPASS];
 #pragma unroll
@@ -567,7 +590,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
         const int n = n0 + (int)dn;
         const bool ok = n < g.N && xx < g.W && yy < g.H;
         const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
-        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * 4) : 0x80000000u;
+        voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * ES) : 0x80000000u;
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
     }
     const int cellbase = wave * 32 + r;
@@ -576,6 +599,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
     const unsigned char* wsrc = wimg + (int64_t)(n0c >> 5) * 4096 + lane * 16;
     const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bimg;
     auto dma_b = [&](int kk, int buf) {   // kk = chunk * 9 + tap; the image holds mirrored taps
+        if constexpr (SBF)
+            if (wave & 1) return;   // the odd waves' pieces are the LOW pieces: unused with one product
         const int chunk = kk / 9, tap = kk - chunk * 9;
         const unsigned char* src = wsrc + ((int64_t)((8 - tap) * nchunks + chunk) * co_tiles) * 4096 + wave * 1024;
         const unsigned dst = lds_b + buf * BTILE + wave * 1024;
@@ -588,15 +613,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
                          : "memory");
         }
     };
-    f32x4 pf[NPASS];
+    using PReg = typename std::conditional<SBF, u32x2, f32x4>::type;   // (integer-typed with SBF: see k_conv_halo3)
+    PReg pf[NPASS];
     auto store_halo = [&]() {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            u32x2 hi, lo;
-            split4<false>(pf[p], hi, lo);
-            *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
-            *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+            if constexpr (SBF) {
+                *reinterpret_cast<u32x2*>(Aimg + awr[p]) = pf[p];
+            } else {
+                u32x2 hi, lo;
+                split4<false>(pf[p], hi, lo);
+                *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
+                *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+            }
         }
+    };
+    auto load_pass = [&](int off) -> PReg {
+        if constexpr (SBF) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0));
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     };
     f32x16 acc[4][TN];   // [class = 2 * (hi % 2) + (wi % 2)]
 #pragma unroll
@@ -611,14 +645,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
         for (int ks = 0; ks < 2; ++ks) {
             const int off = cell_slot_off(cellbase + tapoff, 2 * ks + h);
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Aimg + off);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
+            bf16x8 al = ah;
+            if constexpr (!SBF) al = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int boff = j * 4096 + ks * 2048 + lane * 16;
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bb + boff);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bb + boff + 1024);
-                a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a[j], 0, 0, 0);
-                a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a[j], 0, 0, 0);
+                if constexpr (!SBF) {
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bb + boff + 1024);
+                    a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a[j], 0, 0, 0);
+                    a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a[j], 0, 0, 0);
+                }
                 a[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a[j], 0, 0, 0);
             }
         }
@@ -626,8 +663,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
 
     dma_b(0, 0);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-        pf[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[p], 0, 0));
+    for (int p = 0; p < NPASS; ++p) pf[p] = load_pass((int)voff[p]);
     store_halo();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -635,15 +671,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
 #pragma unroll 1
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
-        const int cbytes = (chunk + 1) * 128;
+        const int cbytes = (chunk + 1) * 32 * ES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kk = chunk * 9 + tap;
             const int cur = kk & 1;
             if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            pf[tap] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     rs_x, more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u, 0, 0));
+            pf[tap] = load_pass(more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u);
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
             // kh = 1: even dx rows, dy row a; kh = 0: odd rows, dy row a + 1; kh = 2: odd rows, dy row a (columns alike)
@@ -690,18 +725,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
             f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
             if (!ok) continue;
             const int64_t pix = ((int64_t)n * g.OH + hi) * g.OW + wi;
-            float* dst = y + pix * g.ldy + nch;
+            typedef SnnStore<SBF> St;
             if (ovec) {
-                if (addend) val += *reinterpret_cast<const f32x4*>(addend + pix * g.ld_add + nch);
-                if (addend2) val += *reinterpret_cast<const f32x4*>(addend2 + pix * g.ld_add2 + nch);
-                *reinterpret_cast<f32x4*>(dst) = val;
+                if (addend) val += St::ld4(addend, pix * g.ld_add + nch);
+                if (addend2) val += St::ld4(addend2, pix * g.ld_add2 + nch);
+                St::st4(y, pix * g.ldy + nch, val);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float o = val[q];
-                    if (addend) o += addend[pix * g.ld_add + nch + q];
-                    if (addend2) o += addend2[pix * g.ld_add2 + nch + q];
-                    dst[q] = o;
+                    if (addend) o += St::ld1(addend, pix * g.ld_add + nch + q);
+                    if (addend2) o += St::ld1(addend2, pix * g.ld_add2 + nch + q);
+                    St::st1(y, pix * g.ldy + nch + q, o);
                 }
             }
         }
@@ -763,6 +798,9 @@ __global__ void k_weight_frag_image(const float* __restrict__ flat_src, unsigned
 
 static unsigned magic_u32(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+// 4 consecutive elements of an activation tensor per access: 16 bytes, or 8 with bf16 storage
+static bool out_aligned(const void* p, bool bf16) { return bf16 ? aligned8(p) : aligned16(p); }
 
 // 0: not covered, 1: padded-strip tiles (rows of <= 78 pixels), 2: 4 x 32 rectangles (any width)
 static int halo_mode(int64_t N, int H, int W, int Cin, int Cout) {
@@ -794,14 +832,18 @@ extern "C" int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, 
 
 extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N,
                                     int H, int W, int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend,
-                                    const float* addend2, int64_t ld_addend2, void* stream) {
+                                    const float* addend2, int64_t ld_addend2, int precision, void* stream) {
     SNN_REQUIRE(dy && wt_image && dx, "snn_conv3x3_s2_dgrad: null pointer");
+    SNN_REQUIRE(precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16S,
+                "snn_conv3x3_s2_dgrad: precision must be SNN_PREC_BF16X3 or SNN_PREC_BF16S (got %d)", precision);
+    const bool sbf = precision == SNN_PREC_BF16S;
     SNN_REQUIRE(s2dgrad_shape_ok(N, H, W, Cin, Ho, Wo, Cout),
                 "snn_conv3x3_s2_dgrad: shape not covered (N %lld, %dx%d -> %dx%d, %d -> %d channels; ask "
                 "snn_conv3x3_s2_dgrad_supported)", (long long)N, H, W, Ho, Wo, Cin, Cout);
     SNN_REQUIRE(lddy >= Cout && lddx >= Cin && lddy % 4 == 0, "snn_conv3x3_s2_dgrad: bad pixel strides (%lld, %lld)",
                 (long long)lddy, (long long)lddx);
-    SNN_REQUIRE(aligned16(dy) && aligned16(wt_image), "snn_conv3x3_s2_dgrad: dy and the weight image must be 16-byte aligned");
+    SNN_REQUIRE((sbf ? aligned8(dy) : aligned16(dy)) && aligned16(wt_image),
+                "snn_conv3x3_s2_dgrad: dy (16 bytes; 8 for bf16) and the weight image (16) must be aligned");
     SNN_REQUIRE(!addend || ld_addend >= Cin, "snn_conv3x3_s2_dgrad: addend pixel stride smaller than channel count");
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv3x3_s2_dgrad: addend2 pixel stride smaller than channel count");
     SNN_REQUIRE((int64_t)4 * Ho * Wo * lddy * 4 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: four dy images must span less than 2 GiB");
@@ -821,14 +863,18 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
     SNN_REQUIRE((int64_t)g.tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: grid too large");
     g.tiles_per_xcd = (int)snn_ceil_div(g.tiles, 8);
     g.magic_pw = magic_u32(g.PW); g.magic_ph = magic_u32(g.PH);
-    g.out_vec = (lddx % 4 == 0) && aligned16(dx) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
-                (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
+    g.out_vec = (lddx % 4 == 0) && out_aligned(dx, sbf) && (!addend || (ld_addend % 4 == 0 && out_aligned(addend, sbf))) &&
+                (!addend2 || (ld_addend2 % 4 == 0 && out_aligned(addend2, sbf)));
     g.bn_partial = nullptr;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
     g.tiles_x = g.tiles_img = 0;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
-    hipLaunchKernelGGL(k_conv_s2dgrad3, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
-                       static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
+    if (sbf)
+        hipLaunchKernelGGL(k_conv_s2dgrad3<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
+                           static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
+    else
+        hipLaunchKernelGGL(k_conv_s2dgrad3<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
+                           static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
     SNN_CHECK_LAUNCH("snn_conv3x3_s2_dgrad");
     return 0;
 }
@@ -925,18 +971,20 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
                                 int64_t ld_addend2, double* bn_partial, int frames_per_step, int* bn_layout,
                                 int precision, void* stream) {
     SNN_REQUIRE(x && w_image && y, "snn_conv3x3_halo: null pointer");
-    SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3,
-                "snn_conv3x3_halo: precision must be SNN_PREC_FP16X3 or SNN_PREC_BF16X3 (got %d)", precision);
+    SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16S,
+                "snn_conv3x3_halo: precision must be SNN_PREC_FP16X3, SNN_PREC_BF16X3 or SNN_PREC_BF16S (got %d)", precision);
+    const bool sbf = precision == SNN_PREC_BF16S;   // x, y, addends bf16; the image holds bf16 pieces (SNN_PREC_BF16X3 image)
     SNN_REQUIRE(halo_shape_ok(N, H, W, Cin, Cout),
                 "snn_conv3x3_halo: shape not covered (N %lld, %dx%d, %d -> %d channels; ask snn_conv3x3_halo_supported)",
                 (long long)N, H, W, Cin, Cout);
     SNN_REQUIRE(ldx >= Cin && ldy >= Cout && ldx % 4 == 0, "snn_conv3x3_halo: bad pixel strides (%lld, %lld)",
                 (long long)ldx, (long long)ldy);
-    SNN_REQUIRE(aligned16(x) && aligned16(w_image), "snn_conv3x3_halo: x and the weight image must be 16-byte aligned");
+    SNN_REQUIRE((sbf ? aligned8(x) : aligned16(x)) && aligned16(w_image),
+                "snn_conv3x3_halo: x (16 bytes; 8 for bf16) and the weight image (16) must be aligned");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv3x3_halo: addend pixel stride smaller than channel count");
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cout, "snn_conv3x3_halo: addend2 pixel stride smaller than channel count");
-    SNN_REQUIRE(!bn_partial || (precision == SNN_PREC_FP16X3 && bn_layout && frames_per_step > 0 && N % frames_per_step == 0 &&
-                                !addend && !addend2),
+    SNN_REQUIRE(!bn_partial || ((precision == SNN_PREC_FP16X3 || sbf) && bn_layout && frames_per_step > 0 &&
+                                N % frames_per_step == 0 && !addend && !addend2),
                 "snn_conv3x3_halo: statistics need the forward arithmetic, bn_layout, no addend and a frames_per_step "
                 "that divides N (%lld frames, %d per step)", (long long)N, frames_per_step);
     SNN_REQUIRE((int64_t)4 * H * W * ldx * 4 < 0x7fffffffLL, "snn_conv3x3_halo: four images must span less than 2 GiB");
@@ -967,8 +1015,8 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     g.tiles = (int)tiles;
     g.tiles_per_xcd = (int)snn_ceil_div(tiles, 8);
     g.magic_pw = magic_u32(g.PW); g.magic_ph = magic_u32(g.PH);
-    g.out_vec = (ldy % 4 == 0) && aligned16(y) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
-                (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
+    g.out_vec = (ldy % 4 == 0) && out_aligned(y, sbf) && (!addend || (ld_addend % 4 == 0 && out_aligned(addend, sbf))) &&
+                (!addend2 || (ld_addend2 % 4 == 0 && out_aligned(addend2, sbf)));
     g.bn_partial = bn_partial;
     g.OH = H; g.OW = W;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
@@ -998,6 +1046,21 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
 #undef SNN_HALO_ABL_LAUNCH
     }
 #endif
+    if (sbf) {
+#define SNN_HALO_LAUNCH_S(CO_)                                                                                       \
+    do {                                                                                                              \
+        if (rect)                                                                                                     \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, false, 0, false, true, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, \
+                               wi, y, g, addend, addend2, nullptr, nullptr, nullptr);                                 \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, false, 0, false, false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
+                               x, wi, y, g, addend, addend2, nullptr, nullptr, nullptr);                              \
+    } while (0)
+        if (co_tile == 128) SNN_HALO_LAUNCH_S(128); else SNN_HALO_LAUNCH_S(64);
+#undef SNN_HALO_LAUNCH_S
+        SNN_CHECK_LAUNCH("snn_conv3x3_halo");
+        return 0;
+    }
     if (co_tile == 128) {
         if (f16) SNN_HALO_LAUNCH(128, true); else SNN_HALO_LAUNCH(128, false);
     } else {

@@ -8,6 +8,7 @@
 // Reference semantics: layer_gen.py:211-214 (BatchNorm2d, per-timestep batch statistics),
 // layer_gen.py:232-235 / 252-254 (norse LIFCell / LICell), tiny_yolo.py:39-44 (LI -> Tanh).
 #include <stdlib.h>
+#include <type_traits>
 #include "snn_common.h"
 
 namespace {
@@ -20,13 +21,51 @@ template <> struct Vec<4> {
     static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 };
+// 8 channels per thread: the bf16-storage scans (16 bytes of bf16 per access; fp32 side tensors as two 16-byte halves)
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <> struct Vec<8> {
+    typedef f32x8 type;
+    static __device__ __forceinline__ f32x8 load(const float* p) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ void store(float* p, f32x8 v) {
+        *reinterpret_cast<f32x4*>(p) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+        *reinterpret_cast<f32x4*>(p + 4) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+    }
+};
 template <> struct Vec<1> {
     typedef float type;
     static __device__ __forceinline__ float load(const float* p) { return *p; }
     static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
 };
+// activation tensors in the storage type (fp32, or bf16 in the bf16-storage mode: snn_common.h SnnStore): element index
+template <int VEC, bool SB> struct VecS;
+template <bool SB> struct VecS<4, SB> {
+    static __device__ __forceinline__ f32x4 load(const float* base, int64_t i) { return SnnStore<SB>::ld4(base, i); }
+    static __device__ __forceinline__ void store(float* base, int64_t i, f32x4 v) { SnnStore<SB>::st4(base, i, v); }
+};
+template <> struct VecS<8, true> {   // 8 bf16 values = 16 bytes
+    static __device__ __forceinline__ f32x8 load(const float* base, int64_t i) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ r = *reinterpret_cast<const u32x4_*>(reinterpret_cast<const unsigned short*>(base) + i);
+        const f32x4 a = snn_unpack_bf16x4(snn_u32x2{r[0], r[1]}), b = snn_unpack_bf16x4(snn_u32x2{r[2], r[3]});
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ void store(float* base, int64_t i, f32x8 v) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const snn_u32x2 a = snn_pack_bf16x4(__builtin_shufflevector(v, v, 0, 1, 2, 3));
+        const snn_u32x2 b = snn_pack_bf16x4(__builtin_shufflevector(v, v, 4, 5, 6, 7));
+        *reinterpret_cast<u32x4_*>(reinterpret_cast<unsigned short*>(base) + i) = u32x4_{a[0], a[1], b[0], b[1]};
+    }
+};
+template <bool SB> struct VecS<1, SB> {
+    static __device__ __forceinline__ float load(const float* base, int64_t i) { return SnnStore<SB>::ld1(base, i); }
+    static __device__ __forceinline__ void store(float* base, int64_t i, float v) { SnnStore<SB>::st1(base, i, v); }
+};
 template <int VEC> __device__ __forceinline__ float& lane(typename Vec<VEC>::type& v, int j);
 template <> __device__ __forceinline__ float& lane<4>(f32x4& v, int j) { return reinterpret_cast<float*>(&v)[j]; }
+template <> __device__ __forceinline__ float& lane<8>(f32x8& v, int j) { return reinterpret_cast<float*>(&v)[j]; }
 template <> __device__ __forceinline__ float& lane<1>(float& v, int) { return v; }
 
 // ------------------------------------------------------------------------------------------
@@ -52,7 +91,7 @@ static StatsPlan stats_plan(int T, int64_t M, int C) {
     return pl;
 }
 
-template <int VEC>
+template <int VEC, bool SB = false>
 __global__ __launch_bounds__(kThreads) void k_bn_stats(const float* __restrict__ y, int64_t ldy, int64_t M, int C,
                                                        int cvb, double* __restrict__ partial) {
     __shared__ double red[kThreads * 2 * VEC];
@@ -71,9 +110,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(const float* __restrict__
         const int64_t m0 = (int64_t)chunk * per;
         int64_t m1 = m0 + per;
         if (m1 > M) m1 = M;
-        const float* base = y + ((int64_t)t * M) * ldy + (int64_t)cg * VEC;
+        const int64_t base = ((int64_t)t * M) * ldy + (int64_t)cg * VEC;   // element index (y: fp32, or bf16 with SB)
         for (int64_t m = m0 + ps; m < m1; m += P) {
-            typename Vec<VEC>::type v = Vec<VEC>::load(base + m * ldy);
+            typename Vec<VEC>::type v = VecS<VEC, SB>::load(y, base + m * ldy);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 double d = (double)lane<VEC>(v, j);
@@ -282,7 +321,11 @@ __global__ void k_bn_running_update(const float* __restrict__ mean, const double
 // of reading one saved value per step.  Half the saved-state memory of mode 1 at the same speed (forward faster,
 // backward slower by about as much); opt-in from functional.LIF_CHECKPOINT_BYTES.
 constexpr int kCkpt = 4;
-template <int NEURON, int VEC, int SAVE>
+#ifndef SNN_SCAN_PREFETCH
+#define SNN_SCAN_PREFETCH 2   // steps of operands in flight ahead of the recurrence (forward scan)
+#endif
+// SB (SNN_SCAN_BF16_STORAGE): y, out, addend and vdec are bf16 tensors (pointers passed as float*, strides in elements)
+template <int NEURON, int VEC, int SAVE, bool SB = false>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     const float* __restrict__ y, int64_t ldy, const float* __restrict__ alpha, const float* __restrict__ beta,
     const float* __restrict__ v0, const float* __restrict__ i0, float* __restrict__ out, int64_t ldo,
@@ -291,6 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     // last_only (SNN_SCAN_LAST_STEP_ONLY): `out` is [M][ldo], only the last timestep's output is kept (the detection
     // head: soda.py:141-144 returns the predictions of the last step) - T-1 of T output stores never happen
     typedef typename Vec<VEC>::type V;
+    static_assert(!SB || SAVE != 2, "the checkpointed scan keeps fp32 checkpoints: not combined with bf16 storage");
     const int cv = C / VEC;
     const int64_t total = M * cv;
     for (int64_t col = (int64_t)blockIdx.x * kThreads + threadIdx.x; col < total;
@@ -310,6 +354,35 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                 for (int j = 0; j < VEC; ++j) lane<VEC>(i, j) = 0.0f;
             }
         }
+        // The operands of a step - y, the BatchNorm affine (alpha, beta)[t][c], the shortcut - are requested kPrefetch steps
+        // ahead of the recurrence and rotate through registers: with the loads inside the step every iteration waited for
+        // its own alpha / beta loads (s_waitcnt vmcnt(0): a full memory latency per timestep, whatever was prefetched
+        // before them).  Steps past the end re-read the last one.  The pipelined loop must be free of branches around its
+        // memory operations (at a control-flow join the compiler's wait-count pass falls back to vmcnt(0)), so it exists
+        // in the two forms the layer-major step uses - BatchNorm affine, all T outputs, with / without a shortcut - and
+        // everything else (no affine, last step only) takes the plain loop with its run-time checks.
+        auto time_loop = [&](auto piped_c, auto add_c) {
+        constexpr bool PIPED = decltype(piped_c)::value;       // affine present, all outputs stored, ADD known
+        constexpr bool ADD = decltype(add_c)::value;
+        constexpr int kPrefetch = PIPED ? SNN_SCAN_PREFETCH : 0;
+        struct StepOps { V x, a, b, ad; };
+        auto fetch_step = [&](int t) {
+            const int tc = t < T ? t : T - 1;
+            const int64_t row = (int64_t)tc * M + m;
+            StepOps o;
+            o.x = VecS<VEC, SB>::load(y, row * ldy + c);
+            if (PIPED || alpha) {
+                o.a = Vec<VEC>::load(alpha + (int64_t)tc * C + c);
+                o.b = Vec<VEC>::load(beta + (int64_t)tc * C + c);
+            }
+            if (PIPED ? ADD : addend != nullptr) o.ad = VecS<VEC, SB>::load(addend, row * ld_add + c);
+            return o;
+        };
+        StepOps sq[kPrefetch > 0 ? kPrefetch : 1];
+        if constexpr (kPrefetch > 0) {
+#pragma unroll
+            for (int k = 0; k < kPrefetch; ++k) sq[k] = fetch_step(k);
+        }
         for (int t = 0; t < T; ++t) {
             const int64_t row = (int64_t)t * M + m;
             if (SAVE == 2 && NEURON == SNN_NEURON_LIF && (t % kCkpt) == 0) {
@@ -317,12 +390,19 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                 Vec<VEC>::store(ck, v);
                 Vec<VEC>::store(ck + M * C, i);
             }
-            V x = Vec<VEC>::load(y + row * ldy + c);
-            if (alpha) {
-                V a = Vec<VEC>::load(alpha + (int64_t)t * C + c);
-                V b = Vec<VEC>::load(beta + (int64_t)t * C + c);
+            StepOps cur;
+            if constexpr (kPrefetch > 0) {
+                cur = sq[0];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) lane<VEC>(x, j) = lane<VEC>(x, j) * lane<VEC>(a, j) + lane<VEC>(b, j);
+                for (int k = 0; k + 1 < kPrefetch; ++k) sq[k] = sq[k + 1];
+                sq[kPrefetch - 1] = fetch_step(t + kPrefetch);
+            } else {
+                cur = fetch_step(t);
+            }
+            V x = cur.x;
+            if (PIPED || alpha) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lane<VEC>(x, j) = lane<VEC>(x, j) * lane<VEC>(cur.a, j) + lane<VEC>(cur.b, j);
             }
             V o, vd;
 #pragma unroll
@@ -364,15 +444,25 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                     }
                 }
             }
-            if (addend) {  // residual shortcut folded into the store
-                V ad = Vec<VEC>::load(addend + row * ld_add + c);
+            if (PIPED ? ADD : addend != nullptr) {  // residual shortcut folded into the store
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(ad, j);
+                for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(cur.ad, j);
             }
-            if (!last_only) Vec<VEC>::store(out + row * ldo + c, o);
-            else if (t == T - 1) Vec<VEC>::store(out + m * ldo + c, o);
+            if (PIPED || !last_only) VecS<VEC, SB>::store(out, row * ldo + c, o);
+            else if (t == T - 1) VecS<VEC, SB>::store(out, m * ldo + c, o);
             if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
-                Vec<VEC>::store(vdec + row * C + c, vd);
+                VecS<VEC, SB>::store(vdec, row * C + c, vd);
+        }
+        };
+        if constexpr (VEC > 1 && SAVE != 2) {
+            if (alpha && !last_only) {
+                if (addend) time_loop(std::true_type{}, std::true_type{});
+                else time_loop(std::true_type{}, std::false_type{});
+            } else {
+                time_loop(std::false_type{}, std::false_type{});
+            }
+        } else {
+            time_loop(std::false_type{}, std::false_type{});
         }
         if (NEURON != SNN_NEURON_NONE) {
             if (vT) Vec<VEC>::store(vT + m * C + c, v);
@@ -404,7 +494,31 @@ struct BwdPlan {
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+static BwdPlan bwd_plan_lds(int T, int64_t M, int C, bool with_sums, int lds_kib);
+
+// The per-wave sum slabs of a block take up to `budget` KiB of LDS, which decides how many blocks a CU holds (64 KiB: 2)
+// and how many channels a block covers.  On the large maps that is the right trade (long pixel runs per block, wide
+// channel runs per pixel).  On the mid-size maps (30x38 x 128..256 channels at B = 5) the 2-per-CU grid is not even full:
+// ~350 blocks whose threads each walk 2 pixel rows x T steps - a serial VALU chain (the masked rows of the NP-row
+// groups compute too) that ran 81 us where the same scan without sums takes 28.  A smaller slab (fewer channels per
+// block, more blocks per CU, one pixel row per thread) shortens the chain; taken only while the plan leaves CUs idle.
 static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
+    BwdPlan best = bwd_plan_lds(T, M, C, with_sums, 64);
+    if (!with_sums || snn_tuning_env("SNN_BWD_LDS64")) return best;
+    for (int kib = 32; kib >= 16; kib /= 2) {
+        const int64_t blocks = (int64_t)best.gx * best.gy;
+        if (blocks >= 2 * (int64_t)snn_num_cu()) break;                      // two blocks per CU: the chip is full
+        // (also tried: the smaller slab whenever the NP-row groups are partly masked - the large maps then run several
+        // rounds of blocks and lose 2x)
+        BwdPlan alt = bwd_plan_lds(T, M, C, with_sums, kib);
+        if (alt.cvb * alt.vec * 4 < 64 && alt.gy > best.gy) break;           // keep >= 64-byte channel runs per pixel (fp32 size)
+        if ((int64_t)alt.gx * alt.gy <= blocks) break;
+        best = alt;
+    }
+    return best;
+}
+
+static BwdPlan bwd_plan_lds(int T, int64_t M, int C, bool with_sums, int lds_kib) {
     BwdPlan pl;
     pl.vec = (C % 4 == 0) ? 4 : 1;
     int cv = C / pl.vec;
@@ -415,8 +529,8 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
         const bool ordered = is_pow2(cvb) || cvb >= 64;
         pl.mode = ordered ? 1 : 2;
         const int slabs = ordered ? kWaves : 1;
-        // LDS budget 64 KiB: slabs * T * cb * 2 floats
-        int64_t max_cvb = (64 * 1024) / ((int64_t)slabs * T * 8 * pl.vec);
+        // LDS budget: slabs * T * cb * 2 floats
+        int64_t max_cvb = ((int64_t)lds_kib * 1024) / ((int64_t)slabs * T * 8 * pl.vec);
         if (max_cvb < 1) max_cvb = 1;
         if (cvb > max_cvb) {
             cvb = (int)max_cvb;
@@ -435,7 +549,8 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
     // time with the tail masked: all blocks are resident at once and finish together.  (A grid-stride loop over
     // kBwdNP-row groups left e.g. 713 groups on 512 blocks: 2 rounds for 1.4 rounds of work.)
     const int64_t rows = snn_ceil_div(M, (int64_t)P);
-    int64_t cap = with_sums ? 2 * snn_num_cu() : snn_max_blocks();  // 64 KiB of LDS per block -> 2 blocks per CU
+    // blocks resident per CU by LDS (160 KiB per CU; 64 KiB slabs: 2, 32 KiB: 4, 16 KiB: 8 = the wave limit)
+    int64_t cap = with_sums ? (int64_t)(128 / lds_kib) * snn_num_cu() : snn_max_blocks();
     if (const char* force = snn_tuning_env("SNN_BWD_CAP")) cap = atoi(force) > 0 ? atoi(force) : cap;  // tuning aid
     cap = cap / pl.gy;
     if (cap < 1) cap = 1;
@@ -451,7 +566,8 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
 // pass could not tell the prefetched loads of step t-1 from the ones step t needs and waited for ALL of them before
 // every pixel (vmcnt(0)): the prefetch bought nothing and the kernel ran at 3.9 TB/s with the texture addresser 16 %
 // busy.  Host-checked: one timestep of every tensor is < 2 GiB.
-template <int NEURON, int VEC, int MODE, bool BUF, int NP>
+// SB (SNN_SCAN_BF16_STORAGE): g_out, state, y and gx are bf16 tensors (pointers passed as float*, strides in elements).
+template <int NEURON, int VEC, int MODE, bool BUF, int NP, bool SB = false>
 __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
@@ -461,6 +577,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     // last_only (SNN_SCAN_LAST_STEP_ONLY; LIF / LI / LI+Tanh): g_out (and LI+Tanh's saved output) are [M][..] tensors of
     // the LAST timestep; the output gradient of every earlier step is zero and nothing is read for it
     typedef typename Vec<VEC>::type V;
+    constexpr int ES = SnnStore<SB>::ES;   // bytes per element of the activation tensors
     constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
     constexpr bool kNeedsState = (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_LI_TANH || kNeedsX);
     extern __shared__ __attribute__((aligned(16))) float red[];  // MODE 1: [wave][T][cb][2]; MODE 2: [T][cb][2]
@@ -504,37 +621,50 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
         if constexpr (BUF) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                og[q] = ok[q] ? (int)((mq[q] * ldg + c) * 4) : -1;
-                os[q] = ok[q] ? (int)((mq[q] * C + c) * 4) : -1;
-                oy[q] = ok[q] ? (int)((mq[q] * ldy + c) * 4) : -1;
+                og[q] = ok[q] ? (int)((mq[q] * ldg + c) * ES) : -1;
+                os[q] = ok[q] ? (int)((mq[q] * C + c) * ES) : -1;
+                oy[q] = ok[q] ? (int)((mq[q] * ldy + c) * ES) : -1;
             }
         }
         auto slab = [&](const float* base, int t, int64_t ld) {  // buffer resource of timestep t of a [T][M][ld] tensor
-            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)t * M * ld), 0, (int)(M * ld * 4),
-                                                     0x00020000);
+            char* b = reinterpret_cast<char*>(const_cast<float*>(base)) + (int64_t)t * M * ld * ES;
+            return __builtin_amdgcn_make_buffer_rsrc(b, 0, (int)(M * ld * ES), 0x00020000);
         };
         auto slab_out = [&](const float* base, int t, int64_t ld) {  // g_out / saved output: all steps, or the last one only
             if (!last_only) return slab(base, t, ld);
-            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, t == T - 1 ? (int)(M * ld * 4) : 0,
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, t == T - 1 ? (int)(M * ld * ES) : 0,
                                                      0x00020000);   // zero records: every load returns 0
         };
-        auto fetch = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
+        // Operand sets in flight hold what the loads return: fp32 quads, or (bf16 storage) the 8 raw bytes of 4 bf16 values -
+        // half the registers, which pays for a THIRD set: with half the bytes per step, one step of prefetch no longer
+        // covers the memory latency (3.0 - 4.5 TB/s measured with two sets against 5 TB/s on fp32 tensors).
+        using R = typename std::conditional<(SB && BUF), snn_u32x2, V>::type;
+        constexpr int DEPTH = (SB && BUF) ? 3 : 2;
+        auto widen = [](const R& r) -> V {
+            if constexpr (SB && BUF) return snn_unpack_bf16x4(r);
+            else return r;
+        };
+        auto bload = [&](const auto& rs, int off) -> R {   // 4 elements of a storage-type tensor (generic: BUF instances only)
+            if constexpr (SB && BUF) return __builtin_bit_cast(snn_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+            else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        };
+        auto fetch = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP]) {
             if constexpr (BUF) {
                 const __amdgpu_buffer_rsrc_t rg = slab_out(g_out, t, ldg);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    go[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rg, og[q], 0, 0));
+                    go[q] = bload(rg, og[q]);
                 if (kNeedsState) {
                     const __amdgpu_buffer_rsrc_t rs = (NEURON == SNN_NEURON_LI_TANH) ? slab_out(state, t, C) : slab(state, t, C);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        st[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, os[q], 0, 0));
+                        st[q] = bload(rs, os[q]);
                 }
                 if (MODE != 0 || kNeedsX) {
                     const __amdgpu_buffer_rsrc_t ry = slab(y, t, ldy);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        yv[q] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ry, oy[q], 0, 0));
+                        yv[q] = bload(ry, oy[q]);
                 }
             } else {
 #pragma unroll
@@ -545,17 +675,17 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         const bool live = !last_only || t == T - 1;
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) lane<VEC>(go[q], j) = lane<VEC>(st[q], j) = 0.0f;
-                        if (live) go[q] = Vec<VEC>::load(g_out + row_o * ldg + c);
+                        if (live) go[q] = VecS<VEC, SB>::load(g_out, row_o * ldg + c);
                         if (kNeedsState) {
-                            if (NEURON != SNN_NEURON_LI_TANH) st[q] = Vec<VEC>::load(state + row * C + c);
-                            else if (live) st[q] = Vec<VEC>::load(state + row_o * C + c);
+                            if (NEURON != SNN_NEURON_LI_TANH) st[q] = VecS<VEC, SB>::load(state, row * C + c);
+                            else if (live) st[q] = VecS<VEC, SB>::load(state, row_o * C + c);
                         }
-                        if (MODE != 0 || kNeedsX) yv[q] = Vec<VEC>::load(y + row * ldy + c);
+                        if (MODE != 0 || kNeedsX) yv[q] = VecS<VEC, SB>::load(y, row * ldy + c);
                     }
                 }
             }
         };
-        auto process = [&](int t, V (&go)[NP], V (&st)[NP], V (&yv)[NP]) {
+        auto process = [&](int t, R (&go_r)[NP], R (&st_r)[NP], R (&yv_r)[NP]) {
             float s1[VEC], s2[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
@@ -567,11 +697,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     b1 = Vec<VEC>::load(beta + (int64_t)t * C + c);
                 }
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
+                for (int q = 0; q < NP; ++q) {
+                    V yq = widen(yv_r[q]);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j)
-                        lane<VEC>(xa[q], j) = alpha ? lane<VEC>(yv[q], j) * lane<VEC>(a1, j) + lane<VEC>(b1, j)
-                                                    : lane<VEC>(yv[q], j);
+                        lane<VEC>(xa[q], j) = alpha ? lane<VEC>(yq, j) * lane<VEC>(a1, j) + lane<VEC>(b1, j) : lane<VEC>(yq, j);
+                }
             }
             [[maybe_unused]] __amdgpu_buffer_rsrc_t rgx;
             if constexpr (BUF) rgx = slab(gx, t, C);
@@ -580,13 +711,17 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 if (!BUF && !ok[q]) continue;  // BUF: lanes without a pixel compute on zeros, their store is dropped
                 const int64_t row = (int64_t)t * M + mq[q];
                 V g;
+                V go_q = widen(go_r[q]);
+                [[maybe_unused]] V st_q, yv_q;
+                if (kNeedsState) st_q = widen(st_r[q]);
+                if (MODE != 0) yv_q = widen(yv_r[q]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    float goj = lane<VEC>(go[q], j);
+                    float goj = lane<VEC>(go_q, j);
                     if (NEURON == SNN_NEURON_NONE) {
                         lane<VEC>(g, j) = goj;
                     } else if (NEURON == SNN_NEURON_LIF) {
-                        float vd = lane<VEC>(st[q], j);
+                        float vd = lane<VEC>(st_q, j);
                         float u = vd - p.v_th;
                         float z = (u > 0.0f) ? 1.0f : 0.0f;
                         float den = p.alpha * fabsf(u) + 1.0f;
@@ -599,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         lane<VEC>(gi[q], j) = g_in;
                         lane<VEC>(g, j) = g_in;
                     } else if (NEURON == SNN_NEURON_SLI) {
-                        const float v_old = lane<VEC>(st[q], j);
+                        const float v_old = lane<VEC>(st_q, j);
                         const float xj = lane<VEC>(xa[q], j);
                         const float s = 1.0f / (1.0f + expf(-(p.v_st - fabsf(v_old))));
                         const float sgn = (v_old > 0.0f) ? 1.0f : ((v_old < 0.0f) ? -1.0f : 0.0f);
@@ -609,7 +744,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         lane<VEC>(gi[q], j) = g_ij;
                         lane<VEC>(g, j) = g_ij * s;
                     } else if (NEURON == SNN_NEURON_SYNAPSE) {
-                        const float p_new = lane<VEC>(st[q], j);
+                        const float p_new = lane<VEC>(st_q, j);
                         const float xj = lane<VEC>(xa[q], j);
                         const float td = ((xj > 0.0f) ? p.tau_sec : p.tau_dis) * p.dt;
                         float gpre = p_new, dg = 1.0f;
@@ -623,7 +758,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     } else {
                         float d = 1.0f;
                         if (NEURON == SNN_NEURON_LI_TANH) {
-                            float o = lane<VEC>(st[q], j);
+                            float o = lane<VEC>(st_q, j);
                             d = 1.0f - o * o;
                         }
                         float g_vn = goj * d + lane<VEC>(gv[q], j);
@@ -634,7 +769,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     }
                     if (MODE != 0) {
                         s1[j] += lane<VEC>(g, j);
-                        s2[j] += lane<VEC>(g, j) * lane<VEC>(yv[q], j);
+                        s2[j] += lane<VEC>(g, j) * lane<VEC>(yv_q, j);
                     }
                 }
                 if (apply_scale) {
@@ -642,12 +777,16 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
                 }
-                if constexpr (BUF)
+                if constexpr (BUF && SB)
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rgx, 0, 0, 0)), snn_pack_bf16x4(g)), rgx,
+                        os[q], 0, 0);
+                else if constexpr (BUF)
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rgx, 0, 0, 0)), g), rgx, os[q],
                         0, 0);
                 else
-                    Vec<VEC>::store(gx + row * C + c, g);
+                    VecS<VEC, SB>::store(gx, row * C + c, g);
             }
             if (MODE == 1) {
                 // lanes l and l ^ stride (stride a multiple of cvb) hold the same channels
@@ -678,14 +817,34 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 }
             }
                 };
-        V goA[NP], stA[NP], yvA[NP], goB[NP], stB[NP], yvB[NP];
-        fetch(T - 1, goA, stA, yvA);
-        for (int t = T - 1; t >= 0; t -= 2) {
-            if (t >= 1) fetch(t - 1, goB, stB, yvB);
-            process(t, goA, stA, yvA);
-            if (t >= 1) {
-                if (t >= 2) fetch(t - 2, goA, stA, yvA);
-                process(t - 1, goB, stB, yvB);
+        R goA[NP], stA[NP], yvA[NP], goB[NP], stB[NP], yvB[NP];
+        if constexpr (DEPTH == 3) {
+            // three sets, two steps ahead; steps below 0 re-read step 0 (no branch around the loads)
+            R goC[NP], stC[NP], yvC[NP];
+            auto fetch0 = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP]) { fetch(t > 0 ? t : 0, go, st, yv); };
+            fetch(T - 1, goA, stA, yvA);
+            fetch0(T - 2, goB, stB, yvB);
+            for (int t = T - 1; t >= 0; t -= 3) {
+                fetch0(t - 2, goC, stC, yvC);
+                process(t, goA, stA, yvA);
+                if (t >= 1) {
+                    fetch0(t - 3, goA, stA, yvA);
+                    process(t - 1, goB, stB, yvB);
+                }
+                if (t >= 2) {
+                    fetch0(t - 4, goB, stB, yvB);
+                    process(t - 2, goC, stC, yvC);
+                }
+            }
+        } else {
+            fetch(T - 1, goA, stA, yvA);
+            for (int t = T - 1; t >= 0; t -= 2) {
+                if (t >= 1) fetch(t - 1, goB, stB, yvB);
+                process(t, goA, stA, yvA);
+                if (t >= 1) {
+                    if (t >= 2) fetch(t - 2, goA, stA, yvA);
+                    process(t - 1, goB, stB, yvB);
+                }
             }
         }
         if (NEURON != SNN_NEURON_NONE) {
@@ -1057,7 +1216,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize_fused(
     }
 }
 
-template <int VEC>
+template <int VEC, bool SB = false>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restrict__ gx, const float* __restrict__ y,
                                                            int64_t ldy, const float* __restrict__ coefA,
                                                            const float* __restrict__ coefB,
@@ -1070,8 +1229,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
         const int64_t row = e / cv;
         const int c = (int)(e % cv) * VEC;
         const int64_t t = row / M;
-        V g = Vec<VEC>::load(gx + row * C + c);
-        V yv = Vec<VEC>::load(y + row * ldy + c);
+        V g = VecS<VEC, SB>::load(gx, row * C + c);
+        V yv = VecS<VEC, SB>::load(y, row * ldy + c);
         V a = Vec<VEC>::load(coefA + t * C + c);
         V b = Vec<VEC>::load(coefB + t * C + c);
         V k = Vec<VEC>::load(coefC + t * C + c);
@@ -1079,17 +1238,17 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
             lane<VEC>(r, j) = lane<VEC>(a, j) * lane<VEC>(g, j) + lane<VEC>(b, j) * lane<VEC>(yv, j) + lane<VEC>(k, j);
-        float* d = dy + row * lddy + c;
         if (accumulate) {
-            V old = Vec<VEC>::load(d);
+            V old = VecS<VEC, SB>::load(dy, row * lddy + c);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) lane<VEC>(r, j) += lane<VEC>(old, j);
         }
-        Vec<VEC>::store(d, r);
+        VecS<VEC, SB>::store(dy, row * lddy + c, r);
     }
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 }  // namespace
 
@@ -1113,6 +1272,18 @@ extern "C" int snn_bn_stats(const float* y, int64_t ldy, int T, int64_t M, int C
     else
         hipLaunchKernelGGL(k_bn_stats<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, y, ldy, M, C, pl.cvb, partial);
     SNN_CHECK_LAUNCH("snn_bn_stats");
+    return 0;
+}
+
+extern "C" int snn_bn_stats_bf16(const float* y, int64_t ldy, int T, int64_t M, int C, double* partial, void* stream) {
+    SNN_REQUIRE(y && partial, "snn_bn_stats_bf16: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && C % 4 == 0 && ldy % 4 == 0 && aligned8(y),
+                "snn_bn_stats_bf16: bad shape (T=%d M=%lld C=%d ldy=%lld; C and ldy multiples of 4, y 8-byte aligned)", T,
+                (long long)M, C, (long long)ldy);
+    StatsPlan pl = stats_plan(T, M, C);
+    dim3 grid(pl.chunks, T, pl.zblocks);
+    hipLaunchKernelGGL((k_bn_stats<4, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, y, ldy, M, C, pl.cvb, partial);
+    SNN_CHECK_LAUNCH("snn_bn_stats_bf16");
     return 0;
 }
 
@@ -1187,8 +1358,10 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
                       float* iT, float* vdec, int ckpt_mode, int T, int64_t M, int C, const snn_neuron_params* p,
                       int flags, void* stream) {
     SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
-    SNN_REQUIRE((flags & ~SNN_SCAN_LAST_STEP_ONLY) == 0, "snn_affine_neuron_fwd: unknown flags 0x%x", flags);
+    SNN_REQUIRE((flags & ~(SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE)) == 0, "snn_affine_neuron_fwd: unknown flags 0x%x",
+                flags);
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
+    const bool sb = (flags & SNN_SCAN_BF16_STORAGE) != 0;   // y, out, addend, vdec are bf16 tensors
     SNN_REQUIRE(!last_only || ((neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH) &&
                                !addend),
                 "snn_affine_neuron_fwd: SNN_SCAN_LAST_STEP_ONLY is for LIF / LI / LI+Tanh without a shortcut");
@@ -1203,12 +1376,51 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
                (!addend || (ld_addend % 4 == 0 && aligned16(addend))))
                   ? 4
                   : 1;
+    if (sb) {   // bf16 tensors: 4 elements = 8 bytes per access
+        const bool ok8 = C % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && aligned8(y) && aligned8(out) && aligned8(vdec) &&
+                         aligned16(alpha) && aligned16(beta) && aligned16(v0) && aligned16(i0) && aligned16(vT) &&
+                         aligned16(iT) && (!addend || (ld_addend % 4 == 0 && aligned8(addend)));
+        SNN_REQUIRE(ok8 && !ckpt_mode && (neuron == SNN_NEURON_NONE || neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI ||
+                                          neuron == SNN_NEURON_LI_TANH),
+                    "snn_affine_neuron_fwd: bf16 storage covers NONE / LIF / LI / LI+Tanh on channel counts and strides that "
+                    "are multiples of 4 (8-byte aligned tensors), without checkpointing");
+        vec = 4;
+        // 8 channels (16 bytes of bf16) per access when the layout allows: the scan is bound by the number of memory
+        // instructions, not by their bytes (8-byte accesses: 3.3 TB/s of bf16 against 5.1 TB/s with fp32 tensors)
+        static const bool no_v8 = snn_tuning_env("SNN_SCAN_NO_VEC8") != nullptr;   // tuning / bisecting aid
+        if (!no_v8 && C % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && aligned16(y) && aligned16(out) && aligned16(vdec) &&
+            (!addend || (ld_addend % 8 == 0 && aligned16(addend))))
+            vec = 8;
+    }
     int64_t total = M * (C / vec);
     // every thread scans the same number of (pixel, channel group) items over all T (grid-stride, tail masked) and
     // all blocks are resident at once: a capped grid with 1.4 items per thread would run 2 rounds for 1.4 of work
     const int64_t per_thread = snn_ceil_div(total, (int64_t)snn_max_blocks() * kThreads);
     int64_t blocks = snn_ceil_div(total, kThreads * per_thread);
     dim3 grid((unsigned)blocks);
+#define SNN_DISPATCH_FWD_S(NEURON, SAVE)                                                                          \
+    do {                                                                                                          \
+        if (vec == 8)                                                                                             \
+            hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 8, SAVE, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p, last_only); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_affine_neuron_fwd<NEURON, 4, SAVE, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
+                               y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld_addend, vT, iT, vdec, T, M, C, *p, last_only); \
+    } while (0)
+    if (sb) {
+        switch (neuron) {
+            case SNN_NEURON_NONE: SNN_DISPATCH_FWD_S(SNN_NEURON_NONE, 0); break;
+            case SNN_NEURON_LIF:
+                if (vdec) SNN_DISPATCH_FWD_S(SNN_NEURON_LIF, 1);
+                else SNN_DISPATCH_FWD_S(SNN_NEURON_LIF, 0);
+                break;
+            case SNN_NEURON_LI: SNN_DISPATCH_FWD_S(SNN_NEURON_LI, 0); break;
+            default: SNN_DISPATCH_FWD_S(SNN_NEURON_LI_TANH, 0); break;
+        }
+        SNN_CHECK_LAUNCH("snn_affine_neuron_fwd");
+        return 0;
+    }
+#undef SNN_DISPATCH_FWD_S
     switch (neuron) {
         case SNN_NEURON_NONE: SNN_DISPATCH_FWD(SNN_NEURON_NONE, 0); break;
         case SNN_NEURON_LIF:
@@ -1285,9 +1497,10 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
                                      double* sums, int T, int64_t M, int C, const snn_neuron_params* p,
                                      int flags, void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
-    SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY)) == 0,
+    SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE)) == 0,
                 "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
+    const bool sb = (flags & SNN_SCAN_BF16_STORAGE) != 0;   // g_out, state, y, gx are bf16 tensors
     SNN_REQUIRE(!last_only || neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH,
                 "snn_affine_neuron_bwd: SNN_SCAN_LAST_STEP_ONLY is for LIF / LI / LI+Tanh");
     SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldg >= C, "snn_affine_neuron_bwd: bad shape");
@@ -1300,7 +1513,15 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     SNN_REQUIRE((alpha == nullptr) == (beta == nullptr), "snn_affine_neuron_bwd: alpha/beta must come together");
     SNN_REQUIRE(!apply_scale || alpha, "snn_affine_neuron_bwd: apply_scale needs alpha");
     BwdPlan pl = bwd_plan(T, M, C, sums != nullptr);
-    if (pl.vec == 4) {
+    if (sb) {
+        const bool ok = pl.vec == 4 && ldg % 4 == 0 && aligned8(g_out) && aligned8(state) && aligned8(gx) && aligned16(g_vT) &&
+                        aligned16(g_iT) && aligned16(alpha) && aligned16(beta) && aligned16(g_v0) && aligned16(g_i0) &&
+                        (!sums || (ldy % 4 == 0 && aligned8(y))) &&
+                        (neuron == SNN_NEURON_NONE || neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI ||
+                         neuron == SNN_NEURON_LI_TANH);
+        SNN_REQUIRE(ok, "snn_affine_neuron_bwd: bf16 storage covers NONE / LIF / LI / LI+Tanh on channel counts and strides "
+                        "that are multiples of 4 (8-byte aligned tensors)");
+    } else if (pl.vec == 4) {
         bool ok = ldg % 4 == 0 && aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) &&
                   aligned16(alpha) && aligned16(beta) && aligned16(gx) && aligned16(g_v0) && aligned16(g_i0) &&
                   (!(sums || needs_x) || (ldy % 4 == 0 && aligned16(y)));
@@ -1313,6 +1534,39 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
     // (blocks with a single pixel row take the one-pixel-per-thread instance: the three empty pixel slots of the
     // four-pixel one are computed and issued in straight-line code - measured 58 us against 45 for the branchy kernel)
     const bool buf_ok = !no_buf && M * ld_max * 4 < 0x7fffffffLL;
+    if (sb) {
+#define SNN_LAUNCH_BWD_S(NEURON, MODE_)                                                                              \
+    do {                                                                                                             \
+        if (buf_ok && pl.rpb == 1)                                                                                   \
+            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 4, MODE_, true, 1, true>), grid, dim3(kThreads), pl.lds_bytes, \
+                               (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta, apply_scale, gx, \
+                               g_v0, g_i0, sums, T, M, C, pl.cvb, *p, last_only);                                    \
+        else if (buf_ok)                                                                                             \
+            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 4, MODE_, true, kBwdNP, true>), grid, dim3(kThreads),      \
+                               pl.lds_bytes, (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta,  \
+                               apply_scale, gx, g_v0, g_i0, sums, T, M, C, pl.cvb, *p, last_only);                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_affine_neuron_bwd<NEURON, 4, MODE_, false, kBwdNP, true>), grid, dim3(kThreads),     \
+                               pl.lds_bytes, (hipStream_t)stream, g_out, ldg, state, y, ldy, g_vT, g_iT, alpha, beta,  \
+                               apply_scale, gx, g_v0, g_i0, sums, T, M, C, pl.cvb, *p, last_only);                   \
+    } while (0)
+#define SNN_DISPATCH_BWD_S(NEURON)                        \
+    do {                                                  \
+        if (pl.mode == 0) SNN_LAUNCH_BWD_S(NEURON, 0);    \
+        else if (pl.mode == 1) SNN_LAUNCH_BWD_S(NEURON, 1); \
+        else SNN_LAUNCH_BWD_S(NEURON, 2);                 \
+    } while (0)
+        switch (neuron) {
+            case SNN_NEURON_NONE: SNN_DISPATCH_BWD_S(SNN_NEURON_NONE); break;
+            case SNN_NEURON_LIF: SNN_DISPATCH_BWD_S(SNN_NEURON_LIF); break;
+            case SNN_NEURON_LI: SNN_DISPATCH_BWD_S(SNN_NEURON_LI); break;
+            default: SNN_DISPATCH_BWD_S(SNN_NEURON_LI_TANH); break;
+        }
+#undef SNN_DISPATCH_BWD_S
+#undef SNN_LAUNCH_BWD_S
+        SNN_CHECK_LAUNCH("snn_affine_neuron_bwd");
+        return 0;
+    }
     switch (neuron) {
         case SNN_NEURON_NONE: SNN_DISPATCH_BWD(SNN_NEURON_NONE); break;
         case SNN_NEURON_LIF: SNN_DISPATCH_BWD(SNN_NEURON_LIF); break;
@@ -1424,5 +1678,21 @@ extern "C" int snn_bn_bwd_apply(const float* gx, const float* y, int64_t ldy, co
         hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y,
                            ldy, coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);
     SNN_CHECK_LAUNCH("snn_bn_bwd_apply");
+    return 0;
+}
+
+extern "C" int snn_bn_bwd_apply_bf16(const float* gx, const float* y, int64_t ldy, const float* coefA, const float* coefB,
+                                     const float* coefC, float* dy, int64_t lddy, int T, int64_t M, int C, int accumulate,
+                                     void* stream) {
+    SNN_REQUIRE(gx && y && coefA && coefB && coefC && dy, "snn_bn_bwd_apply_bf16: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C && lddy >= C && C % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 &&
+                    aligned8(gx) && aligned8(y) && aligned8(dy) && aligned16(coefA) && aligned16(coefB) && aligned16(coefC),
+                "snn_bn_bwd_apply_bf16: bad shape (C and strides multiples of 4, bf16 tensors 8-byte aligned)");
+    int64_t total = (int64_t)T * M * (C / 4);
+    int64_t blocks = snn_ceil_div(total, kThreads);
+    if (blocks > snn_max_blocks()) blocks = snn_max_blocks();
+    hipLaunchKernelGGL((k_bn_bwd_apply<4, true>), dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, gx, y, ldy,
+                       coefA, coefB, coefC, dy, lddy, T, M, C, accumulate);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_apply_bf16");
     return 0;
 }

@@ -68,7 +68,8 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 // used to size the workspace in that case - the caller checks the same conditions before planning)
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
-                          int nprod /* 3: bf16 x 3, 1: bf16 x 1 */, hipStream_t st);
+                          int nprod /* 3: bf16 x 3, 1: bf16 x 1 */, bool bf16_storage /* x, dy bf16 (nprod 1) */,
+                          hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -81,3 +82,53 @@ __host__ __device__ inline int64_t snn_bn_partial_index(int64_t t, int64_t chunk
     return ((t * C + c) * chunks + chunk) * 2;
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- activation storage codec (the opt-in bf16-STORAGE throughput mode, SNN_PREC_BF16S / SNN_SCAN_BF16_STORAGE): an
+// activation tensor in HBM is fp32, or bf16 = the upper half of the fp32 pattern, rounded to nearest even when stored.
+// Kernels compute in fp32 registers either way; SnnStore<BF> moves 1 or 4 consecutive elements at ELEMENT index i.
+#ifdef __HIPCC__
+typedef unsigned snn_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 snn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float snn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 snn_unpack_bf16x4(snn_u32x2 r) {
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, r[0] << 16);
+    v[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r[1] << 16);
+    v[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ snn_u32x2 snn_pack_bf16x4(f32x4 v) {
+    const snn_bf16x2 a = __builtin_convertvector(snn_f32x2{v[0], v[1]}, snn_bf16x2);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    const snn_bf16x2 b = __builtin_convertvector(snn_f32x2{v[2], v[3]}, snn_bf16x2);
+    return snn_u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+template <bool BF> struct SnnStore;
+template <> struct SnnStore<false> {
+    static constexpr int ES = 4;   // bytes per element
+    static __device__ __forceinline__ f32x4 ld4(const void* base, int64_t i) {
+        return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + i);
+    }
+    static __device__ __forceinline__ float ld1(const void* base, int64_t i) { return static_cast<const float*>(base)[i]; }
+    static __device__ __forceinline__ void st4(void* base, int64_t i, f32x4 v) {
+        *reinterpret_cast<f32x4*>(static_cast<float*>(base) + i) = v;
+    }
+    static __device__ __forceinline__ void st1(void* base, int64_t i, float v) { static_cast<float*>(base)[i] = v; }
+};
+template <> struct SnnStore<true> {
+    static constexpr int ES = 2;
+    static __device__ __forceinline__ f32x4 ld4(const void* base, int64_t i) {
+        return snn_unpack_bf16x4(*reinterpret_cast<const snn_u32x2*>(static_cast<const unsigned short*>(base) + i));
+    }
+    static __device__ __forceinline__ float ld1(const void* base, int64_t i) {
+        return __builtin_bit_cast(float, (unsigned)static_cast<const unsigned short*>(base)[i] << 16);
+    }
+    static __device__ __forceinline__ void st4(void* base, int64_t i, f32x4 v) {
+        *reinterpret_cast<snn_u32x2*>(static_cast<unsigned short*>(base) + i) = snn_pack_bf16x4(v);
+    }
+    static __device__ __forceinline__ void st1(void* base, int64_t i, float v) {
+        const snn_bf16x2 a = __builtin_convertvector(snn_f32x2{v, 0.f}, snn_bf16x2);
+        static_cast<unsigned short*>(base)[i] = (unsigned short)(__builtin_bit_cast(unsigned, a) & 0xffffu);
+    }
+};
+#endif

@@ -28,6 +28,7 @@
 // Determinism: every block accumulates in a fixed order and the slabs are summed in slab order (k_wgrad_reduce).
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "snn_common.h"
 
 #ifdef SNN_TUNING
@@ -82,11 +83,15 @@ __device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
 }
 
-template <int WCO, int WK, int S, int NPROD>   // NPROD: 3 = bf16 x 3 (hi + lo pieces), 1 = bf16 x 1 (hi pieces only)
+// SB (bf16-storage mode, NPROD 1): x and dy are bf16 tensors - the halo goes to LDS as it arrives, the dy fragment is
+// eight 2-byte loads; nothing is converted.
+template <int WCO, int WK, int S, int NPROD, bool SB = false>   // NPROD: 3 = bf16 x 3 (hi + lo pieces), 1 = bf16 x 1 (hi pieces only)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, HaloGeom g) {
     static_assert(WCO * WK == 4 && (S == 1 || S == 2), "4 waves; stride 1 or 2");
+    static_assert(!SB || NPROD == 1, "bf16 storage: one product");
+    constexpr int ES = SB ? 2 : 4;   // bytes per activation element in HBM
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE];  // hi image, lo image
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,14 +140,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
         q.rv = g.OH - q.oy0 < g.R ? g.OH - q.oy0 : g.R;
         q.cwv = g.OW - q.ox0 < g.CW ? g.OW - q.ox0 : g.CW;
         const int64_t ipix = (int64_t)g.H * g.W, opix = (int64_t)g.OH * g.OW;
-        q.rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)img * ipix * g.ldx), 0,
-                                                   (int)(((ipix - 1) * g.ldx + g.Cin) * 4), 0x00020000);
-        q.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (int64_t)img * opix * g.lddy), 0,
-                                                   (int)(((opix - 1) * g.lddy + g.Cout) * 4), 0x00020000);
+        q.rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(x) + (int64_t)img * ipix * g.ldx * ES), 0,
+            (int)(((ipix - 1) * g.ldx + g.Cin) * ES), 0x00020000);
+        q.rs_d = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(dy) + (int64_t)img * opix * g.lddy * ES), 0,
+            (int)(((opix - 1) * g.lddy + g.Cout) * ES), 0x00020000);
         return q;
     };
 
-    f32x4 st[NJ];  // halo of the NEXT patch on its way to LDS
+    // halo of the NEXT patch on its way to LDS: 4 fp32 values, or (SB) 4 bf16 values as two dwords (integer-typed: carried
+    // in float lanes and bit-cast back per element, hipcc 7.2 narrows the 8-byte buffer load to 4 bytes)
+    using SReg = typename std::conditional<SB, u32x2, f32x4>::type;
+    SReg st[NJ];
     // `opq` is an opaque zero, re-made per patch: without it the compiler hoists the 16 (row, column) pairs of the
     // staging slots out of the patch loop into VGPRs that the B-fragment double buffer needs
     auto load_halo = [&](const Patch& q, int opq) {
@@ -153,9 +163,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
             const int hr = div_magic2(hl, g.m_hc), hc = hl - hr * g.HC;
             const int iy = iy0 + hr, ix = ix0 + hc;
             const bool ok = (hl < g.halo) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-            const int off = ((iy * g.W + ix) * (int)g.ldx + ci0 + 4 * sl8) * 4;
+            const int off = ((iy * g.W + ix) * (int)g.ldx + ci0 + 4 * sl8) * ES;
             const int voff = off | -(int)!ok | -(g.ablate >> 1 & 1);  // all ones: out of range -> zeros (no branch)
-            st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q.rs_x, voff, 0, 0));
+            if constexpr (SB) st[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(q.rs_x, voff, 0, 0));
+            else st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q.rs_x, voff, 0, 0));
         }
     };
     auto write_halo = [&](int opq) {
@@ -164,9 +175,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
             const int hl = sps + 32 * j + opq;
             const int hr = div_magic2(hl, g.m_hc), hc = hl - hr * g.HC;
             const int sp = hr * g.HWD + (S == 1 ? hc : (hc & 1) * g.HWD2 + (hc >> 1));
-            unsigned h0, l0, h1, l1;
-            split_bf16(st[j][0], st[j][1], h0, l0);
-            split_bf16(st[j][2], st[j][3], h1, l1);
+            unsigned h0, l0 = 0, h1, l1 = 0;
+            if constexpr (SB) {
+                h0 = st[j][0];
+                h1 = st[j][1];
+            } else {
+                split_bf16(st[j][0], st[j][1], h0, l0);
+                split_bf16(st[j][2], st[j][3], h1, l1);
+            }
             if (hl < g.halo) {
                 *reinterpret_cast<u32x2*>(smem + sp * 64 + sl8 * 8) = u32x2{h0, h1};
                 if constexpr (NPROD == 3) *reinterpret_cast<u32x2*>(smem + PLANE + sp * 64 + sl8 * 8) = u32x2{l0, l1};
@@ -183,17 +199,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
     // dy fragment of K-step ks: 8 consecutive pixels of ONE patch row (CW is a multiple of 8) of this lane's channel;
     // zeros (offset -1) for pixels outside the patch / the image and for ks past the last step - the prefetch needs
     // no branch.  The same (row, first column) also places the B fragment: both operands use k = 16 ks + 8 (lane / 32).
-    float araw[8];
-    const int lddy4 = (int)g.lddy * 4;
+    using ARaw = typename std::conditional<SB, unsigned, float>::type;   // SB: the bf16 value in the low half
+    ARaw araw[8];
+    const int lddy4 = (int)g.lddy * ES;   // bytes per dy pixel
     auto load_a = [&](const Patch& q, int ks) {
         const int t0 = 16 * ks + 8 * ah;
         const int rr = div_magic2(t0, g.m_cw), cc = t0 - rr * g.CW;
-        const int off = ((q.oy0 + rr) * g.OW + q.ox0 + cc) * lddy4 + (co0 + ar) * 4;
+        const int off = ((q.oy0 + rr) * g.OW + q.ox0 + cc) * lddy4 + (co0 + ar) * ES;
         const int lim = (ks < g.nks && rr < q.rv) ? q.cwv - cc : 0;   // valid pixels of this group of 8
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int voff = (j < lim ? off + j * lddy4 : -1) | -(g.ablate & 1);
-            araw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(q.rs_d, voff, 0, 0));
+            if constexpr (SB)   // the bf16 value in the low half
+                araw[j] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(q.rs_d, voff, 0, 0);
+            else
+                araw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(q.rs_d, voff, 0, 0));
         }
     };
 
@@ -229,7 +249,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
             // ---- A: split the fragment fetched one step ago, fetch the next one (masked past the last step)
             unsigned ahw[4], alw[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16(araw[2 * e], araw[2 * e + 1], ahw[e], alw[e]);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (SB) {
+                    ahw[e] = araw[2 * e] | (araw[2 * e + 1] << 16);
+                    alw[e] = 0;
+                } else {
+                    split_bf16(araw[2 * e], araw[2 * e + 1], ahw[e], alw[e]);
+                }
+            }
             const bf16x8 Ah = __builtin_bit_cast(bf16x8, u32x4{ahw[0], ahw[1], ahw[2], ahw[3]});
             const bf16x8 Al = __builtin_bit_cast(bf16x8, u32x4{alw[0], alw[1], alw[2], alw[3]});
             load_a(cur, ks + WK);
@@ -334,6 +361,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 }  // namespace
 
@@ -405,10 +433,11 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
-                          int nprod, hipStream_t st) {
+                          int nprod, bool bf16_storage, hipStream_t st) {
     // 32-bit byte offsets inside one image (buffer addressing)
     if ((int64_t)H * W * ldx * 4 >= 0x7fffffffLL || (int64_t)Ho * Wo * lddy * 4 >= 0x7fffffffLL) return -1;
-    if (ldx % 4 != 0 || !aligned16(x)) return -1;
+    if (ldx % 4 != 0 || !(bf16_storage ? aligned8(x) : aligned16(x))) return -1;
+    if (bf16_storage && ((reinterpret_cast<uintptr_t>(dy) & 1u) || nprod != 1)) return -1;
     HaloGeom g;
     g.H = H; g.W = W; g.Cin = Cin; g.OH = Ho; g.OW = Wo; g.Cout = Cout; g.stride = stride;
     g.ldx = ldx; g.lddy = lddy;
@@ -425,7 +454,11 @@ int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx
     dim3 grid((unsigned)nblocks);
 #define SNN_HALO_LAUNCH(WCO_, WK_)                                                                                  \
     do {                                                                                                            \
-        if (stride == 1 && nprod == 3)                                                                              \
+        if (bf16_storage && stride == 1)                                                                            \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (bf16_storage)                                                                                      \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 1, true>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (stride == 1 && nprod == 3)                                                                         \
             hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 3>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
         else if (nprod == 3)                                                                                        \
             hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 3>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \

@@ -89,6 +89,35 @@ def get_backward_precision() -> str:
     return _backward_precision
 
 
+# ------------------------------------------------------------------------------------------- activation storage
+# "fp32" (default, the parity path): every activation tensor is fp32 in HBM.
+# "bf16": the opt-in bf16-STORAGE throughput mode (the dtype BASELINE configs[1] names).  The wide tensors of a layer-major
+#   step - convolution outputs y, spikes / neuron outputs, saved decayed potentials, gradients gx / dy / dx - are bf16 in
+#   HBM (half the bytes of every HBM-bound kernel); neuron state (v, i) stays fp32 in registers across T, BatchNorm
+#   statistics / coefficients, weights, weight gradients and the optimiser stay fp32, accumulation is fp32 (spikes are
+#   exact in bf16).  Convolutions multiply the stored bf16 activations by bf16-rounded weights: one MFMA product
+#   (SNN_PREC_BF16S).  The event frames stay fp32 ({0,1}: two channels), and so does everything behind the head's
+#   last-step read-out (a few frames).  Not a parity mode: 8 significant bits per stored value; stated tolerances in
+#   tests/test_gpu_bf16_storage.py.  The mode is decided where the event frames enter (the Cin = 2 layer writes bf16) and
+#   follows the tensors from there: an operator works in the storage type of its input.
+_BF16 = torch.bfloat16
+STORAGE_MODES = {"fp32": _F32, "bf16": _BF16}
+_activation_storage = _checked(os.environ.get("SNN_ACTIVATION_STORAGE") or "fp32", STORAGE_MODES,
+                               "SNN_ACTIVATION_STORAGE: storage")
+
+
+def set_activation_storage(mode: str) -> None:
+    """"fp32" (default) or "bf16" (opt-in throughput mode, see above)."""
+    global _activation_storage
+    if mode not in STORAGE_MODES:
+        raise ValueError(f"activation storage must be one of {sorted(STORAGE_MODES)}, got {mode!r}")
+    _activation_storage = mode
+
+
+def get_activation_storage() -> str:
+    return _activation_storage
+
+
 def _prec_codes(forward: Optional[str], backward: Optional[str]) -> Tuple[int, int]:
     """Per-call ``precision`` arguments: the layer's own modes, else the session defaults."""
     return (FORWARD_MODES[_checked(forward or _forward_precision, FORWARD_MODES, "forward")],
@@ -148,11 +177,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _require_device(t: torch.Tensor, what: str) -> None:
+def _require_device(t: torch.Tensor, what: str, bf16_ok: bool = False) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what}: tensor is on {t.device}; the MI355X path has no CPU fallback "
                            "(move the model and its inputs to a HIP device)")
-    if t.dtype != _F32:
+    if t.dtype == _BF16 and not bf16_ok:
+        raise RuntimeError(f"{what}: this operator has no bf16-storage form (convolutions, Norm + LIF / LI / LI+Tanh / "
+                           "none, and the Dense / Residual merges do); run the model with activation storage \"fp32\"")
+    if t.dtype != _F32 and t.dtype != _BF16:
         raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
 
 
@@ -200,14 +232,15 @@ def _cl_view(buf: torch.Tensor) -> torch.Tensor:
     return buf.permute(list(range(nd - 3)) + [nd - 1, nd - 3, nd - 2])
 
 
-def _new_cl(lead: Sequence[int], C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
-    return _cl_view(torch.empty((*lead, H, W, C), device=like.device, dtype=_F32))
+def _new_cl(lead: Sequence[int], C: int, H: int, W: int, like: torch.Tensor, dtype=None) -> torch.Tensor:
+    """Dense channels-last tensor on ``like``'s device, in ``like``'s storage type unless ``dtype`` says otherwise."""
+    return _cl_view(torch.empty((*lead, H, W, C), device=like.device, dtype=dtype or like.dtype))
 
 
 def _alias(root: torch.Tensor, storage_offset: int, T: int, B: int, C: int, H: int, W: int, ld: int) -> torch.Tensor:
     """A fresh tensor (no autograd view relation) over ``root``'s storage: logical ``[T,B,C,H,W]``,
     channels-last with pixel stride ``ld``.  Only the HIP kernels write through such aliases."""
-    t = torch.empty(0, device=root.device, dtype=_F32)
+    t = torch.empty(0, device=root.device, dtype=root.dtype)
     t.set_(root.untyped_storage(), storage_offset, (T, B, C, H, W), (B * H * W * ld, H * W * ld, 1, W * ld, ld))
     return t
 
@@ -221,12 +254,14 @@ class ConcatPromise:
         self.total_c, self.parent = total_c, parent
         self.buf: Optional[torch.Tensor] = None
 
-    def get(self, T: int, B: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+    def get(self, T: int, B: int, H: int, W: int, like: torch.Tensor, dtype=None) -> torch.Tensor:
         if self.buf is None:
             if self.parent is not None:
-                self.buf = self.parent.tensor(T, B, self.total_c, H, W, like)
+                self.buf = self.parent.tensor(T, B, self.total_c, H, W, like, dtype)
             else:
-                self.buf = _new_cl((T, B), self.total_c, H, W, like)
+                self.buf = _new_cl((T, B), self.total_c, H, W, like, dtype)
+        if self.buf.dtype != (dtype or like.dtype):
+            raise RuntimeError("Dense merge: branches store their outputs in different types (fp32 / bf16 storage mixed)")
         if tuple(self.buf.shape) != (T, B, self.total_c, H, W):
             raise RuntimeError(f"Dense merge: branch outputs differ in shape: {tuple(self.buf.shape)} vs "
                                f"{(T, B, self.total_c, H, W)}")
@@ -239,10 +274,10 @@ class Dest:
     def __init__(self, promise: ConcatPromise, off: int, c: int):
         self.promise, self.off, self.c = promise, off, c
 
-    def tensor(self, T: int, B: int, C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+    def tensor(self, T: int, B: int, C: int, H: int, W: int, like: torch.Tensor, dtype=None) -> torch.Tensor:
         if C != self.c:
             raise RuntimeError(f"destination slice holds {self.c} channels, operator produces {C}")
-        buf = self.promise.get(T, B, H, W, like)
+        buf = self.promise.get(T, B, H, W, like, dtype)
         return _alias(buf, buf.storage_offset() + self.off, T, B, C, H, W, cl_stride(buf))
 
     def holds(self, x: torch.Tensor) -> bool:
@@ -255,15 +290,19 @@ class Dest:
                 and tuple(x.shape[:2]) == tuple(buf.shape[:2]) and tuple(x.shape[3:]) == tuple(buf.shape[3:]))
 
 
-def _out_tensor(dest: Optional[Dest], T: int, B: int, C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
-    return dest.tensor(T, B, C, H, W, like) if dest is not None else _new_cl((T, B), C, H, W, like)
+def _out_tensor(dest: Optional[Dest], T: int, B: int, C: int, H: int, W: int, like: torch.Tensor, dtype=None) -> torch.Tensor:
+    return dest.tensor(T, B, C, H, W, like, dtype) if dest is not None else _new_cl((T, B), C, H, W, like, dtype)
 
 
 def _raw_to_cl(x: torch.Tensor) -> torch.Tensor:
     """Non-differentiable layout change to (possibly channel-sliced) channels-last memory."""
     if cl_stride(x) is not None:
         return x
-    _require_device(x, "layout")
+    _require_device(x, "layout", bf16_ok=True)
+    if x.dtype == _BF16:   # (rare: bf16 tensors are born channels-last) torch's strided copy
+        out = _new_cl(x.shape[:-3], *x.shape[-3:], x)
+        out.copy_(x)
+        return out
     xc = x.contiguous()
     lead, (C, H, W) = xc.shape[:-3], xc.shape[-3:]
     n = 1
@@ -284,6 +323,9 @@ def _raw_dense_cl(x: torch.Tensor) -> torch.Tensor:
     for d in lead:
         n *= d
     out = _new_cl(lead, C, H, W, x)
+    if x.dtype == _BF16:
+        out.copy_(x)
+        return out
     _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr(), C, n * H * W, C, _stream())
     return out
 
@@ -291,6 +333,8 @@ def _raw_dense_cl(x: torch.Tensor) -> torch.Tensor:
 def _raw_to_nchw(x: torch.Tensor) -> torch.Tensor:
     if x.is_contiguous():
         return x
+    if x.dtype == _BF16:
+        return x.contiguous()
     x = _raw_dense_cl(x)
     lead, (C, H, W) = x.shape[:-3], x.shape[-3:]
     n = 1
@@ -451,14 +495,14 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
         _hip.call("snn_conv3x3_halo_bn", rec.gx.data_ptr(), rec.y.data_ptr(), rec.coef.data_ptr(), B, dy_out.data_ptr(),
                   wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cout, Cin, addend, ld_add, addend2, ld_add2, st)
-    elif (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
+    elif (prec in _HALO_BWD_PRECS and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
             and _hip.query("snn_conv3x3_s2_dgrad_supported", T * B, H, W, Cin, Ho, Wo, Cout)):
         # stride 2: all four phase classes of dx from ONE staged pass over dy (k_conv_s2dgrad3)
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
         _hip.call("snn_conv3x3_s2_dgrad", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin, Ho,
-                  Wo, Cout, addend, ld_add, addend2, ld_add2, st)
-    elif (prec == _hip.PREC_BF16X3 and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
+                  Wo, Cout, addend, ld_add, addend2, ld_add2, prec, st)
+    elif (prec in _HALO_BWD_PRECS and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
         # dx = conv3x3(dy, mirrored taps of w^T): the halo-resident kernel with the data gradient's weight image
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
@@ -484,6 +528,8 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
 # Halo-resident 3x3 kernel (csrc/conv_halo.hip) for the 64 / 128-channel stride-1 layers, forward and data gradient
 # (SNN_NO_HALO_CONV: tuning / bisecting aid - the implicit GEMM everywhere)
 USE_HALO_CONV = not os.environ.get("SNN_NO_HALO_CONV")
+# backward modes the halo kernels take; both read the bf16 x 3 image of the transposed weights (bf16 storage: hi pieces only)
+_HALO_BWD_PRECS = (_hip.PREC_BF16X3, _hip.PREC_BF16S)
 
 
 def _halo_ok(N: int, H: int, W: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int) -> bool:
@@ -537,7 +583,7 @@ def reset_backward_state() -> None:
 def _apply_pending(pend: PendingBnApply) -> None:
     """The classic second phase, in place: gx becomes dy."""
     T, B, C, H, W = pend.dims
-    _hip.call("snn_bn_bwd_apply", pend.gx.data_ptr(), pend.y.data_ptr(), cl_stride(pend.y), pend.coef[0].data_ptr(),
+    _hip.call("snn_bn_bwd_apply_bf16" if pend.gx.dtype == _BF16 else "snn_bn_bwd_apply", pend.gx.data_ptr(), pend.y.data_ptr(), cl_stride(pend.y), pend.coef[0].data_ptr(),
               pend.coef[1].data_ptr(), pend.coef[2].data_ptr(), pend.gx.data_ptr(), C, T, B * H * W, C, 0, _stream())
 
 
@@ -561,11 +607,15 @@ class _Conv2d(Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None, bn_out=None):
-        _require_device(x, "conv2d input")
+        _require_device(x, "conv2d input", bf16_ok=True)
         fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         _require_device(weight, "conv2d weight")
         T, B, Cin, H, W = _dims5(x)
         Cout, Cin_w, KH, KW = weight.shape
+        # bf16 storage: follows the input; enters at the event-frame layer (fp32 {0,1} frames in, bf16 out)
+        sb = x.dtype == _BF16 or (_activation_storage == "bf16" and Cin == 2 and (KH, KW) == (3, 3))
+        if sb:
+            fwd_prec = bwd_prec = _hip.PREC_BF16S
         if Cin_w != Cin:
             raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {Cin_w}")
         Ho = (H + 2 * pad - KH) // stride + 1
@@ -573,7 +623,7 @@ class _Conv2d(Function):
         x = _raw_to_cl(x)
         w = weight.detach()
         w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
-        y = _out_tensor(dest, T, B, Cout, Ho, Wo, x)
+        y = _out_tensor(dest, T, B, Cout, Ho, Wo, x, _BF16 if sb else None)
         partial = layout = None
         if bn_out is not None:  # a train-mode BatchNorm follows: its statistics come out of this kernel's epilogue
             n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", T * B, B, Ho, Wo, Cout)
@@ -585,10 +635,14 @@ class _Conv2d(Function):
                 and getattr(weight, "_snn_w16", None) is not None and weight._snn_wt_version == weight._version):
             w16 = weight._snn_w16.data_ptr()   # a tensor view on the parameter: alive as long as the parameter is
         halo = _halo_ok(T * B, H, W, Cin, Cout, KH, KW, stride, pad) and cl_stride(x) % 4 == 0
-        if halo and fwd_prec == _hip.PREC_FP16X3:
+        if halo and fwd_prec in (_hip.PREC_FP16X3, _hip.PREC_BF16S):
+            # the image holds fp16 pieces (fp16 x 3) or bf16 pieces (bf16 storage: the hi pieces are the rounded weights)
+            img_prec = _hip.PREC_BF16X3 if sb else _hip.PREC_FP16X3
             img = _cached_image(weight, "_snn_wfrag") if w_ohwi is w else None
+            if img is not None and getattr(weight, "_snn_wfrag_prec", _hip.PREC_FP16X3) != img_prec:
+                img = None
             if img is None:
-                img = _frag_image(w_ohwi, Cout, Cin, 0, _hip.PREC_FP16X3)
+                img = _frag_image(w_ohwi, Cout, Cin, 0, img_prec)
             _hip.call("snn_conv3x3_halo", x.data_ptr(), cl_stride(x), img.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
                       H, W, Cin, Cout, None, 0, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
         else:
@@ -616,7 +670,7 @@ class _Conv2d(Function):
         pend = _PENDING_APPLY.pop(gy.data_ptr(), None)
         if pend is not None:
             fused = (not ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.slot is not None
-                     and pend.dims == (T, B, Cout, Ho, Wo) and cl_stride(pend.y) % 4 == 0
+                     and pend.gx.dtype == _F32 and pend.dims == (T, B, Cout, Ho, Wo) and cl_stride(pend.y) % 4 == 0
                      and _hip.query("snn_conv2d_wgrad_bn_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad))
             if fused:
                 # dy is formed while the weight-gradient kernel reads gx and y: no apply pass, no dy tensor
@@ -711,8 +765,10 @@ class _ComposedConv1x1(Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, slot1, slot2, dest, acc, prec=None):
-        _require_device(x, "conv2d input")
+        _require_device(x, "conv2d input", bf16_ok=True)
         fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
+        if x.dtype == _BF16:
+            fwd_prec = bwd_prec = _hip.PREC_BF16S
         T, B, Cin, H, W = _dims5(x)
         C1, C2 = w1.shape[0], w2.shape[0]
         if w1.shape[1] != Cin or w2.shape[1] != C1 or tuple(w1.shape[2:]) != (1, 1) or tuple(w2.shape[2:]) != (1, 1):
@@ -785,6 +841,9 @@ class _ComposedConv1x1(Function):
 
 def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: Optional[Dest] = None,
                      forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
+    if x.dtype == _BF16 and (w1.shape[1] % 32 or w2.shape[0] % 32):   # (see conv2d)
+        y = composed_conv1x1(x.float(), w1, w2, None, forward_precision, backward_precision).to(_BF16)
+        return place(y, dest) if dest is not None else y
     seq, single = as_sequence(x)
     y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq),
                                _prec_codes(forward_precision, backward_precision))
@@ -808,6 +867,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
     ``bn_stats``: the result feeds a train-mode BatchNorm - the kernel also emits that layer's statistics partials
     (attached to the result as ``_snn_bn_partial``; ``affine_neuron`` picks them up and skips its own pass over y).
     """
+    if x.dtype == _BF16 and (weight.shape[1] % 32 or weight.shape[0] % 32):
+        # bf16 storage: the kernels want whole 32-channel k-steps (forward: Cin, data gradient: Cout); other layers - a
+        # prediction head applied to every timestep - take the fp32 kernels between two conversions
+        y = conv2d(x.float(), weight, stride, padding, None, forward_precision, backward_precision, False).to(_BF16)
+        return place(y, dest) if dest is not None else y
     seq, single = as_sequence(x)
     bn_out = [] if bn_stats else None
     y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq),
@@ -870,7 +934,11 @@ class _AffineNeuron(Function):
     def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
          sync_group, bn_hint, last_only, defer_apply) = cfg
-        _require_device(y, "norm/neuron input")
+        _require_device(y, "norm/neuron input", bf16_ok=True)
+        sb = y.dtype == _BF16   # bf16 storage: y, out, the saved per-step state and the gradients; (v, i) and all sums fp32
+        if sb and (neuron not in (_hip.NEURON_NONE, _hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH) or y.shape[-3] % 4):
+            raise RuntimeError("bf16 storage: Norm + none / LIF / LI / LI+Tanh with a multiple of 4 channels only")
+        sb_flag = _hip.SCAN_BF16_STORAGE if sb else 0
         ctx.set_materialize_grads(False)  # unused final-state outputs must arrive as None, not as zero tensors
         y = _raw_to_cl(y)
         ldy = cl_stride(y)
@@ -902,7 +970,8 @@ class _AffineNeuron(Function):
                     n_part = _hip.query("snn_bn_stats_partial_size", T, M, C)
                     partial = torch.empty((n_part,), device=dev, dtype=torch.float64)
                     chunks = rpc = 0
-                    _hip.call("snn_bn_stats", y.data_ptr(), ldy, T, M, C, partial.data_ptr(), st)
+                    _hip.call("snn_bn_stats_bf16" if sb else "snn_bn_stats", y.data_ptr(), ldy, T, M, C,
+                              partial.data_ptr(), st)
                 if sync_group is None:
                     _hip.call("snn_bn_stats_finalize", partial.data_ptr(), chunks, rpc, T, M, C, g_ptr, b_ptr, eps, momentum,
                               _ptr(running_mean), _ptr(running_var), 0, mean.data_ptr(), invstd.data_ptr(),
@@ -927,20 +996,20 @@ class _AffineNeuron(Function):
         else:
             out = _out_tensor(dest, T, B, C, H, W, y)
         has_state = neuron != _hip.NEURON_NONE
-        vT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
-        iT = _new_cl((B,), C, H, W, y) if has_state else torch.empty(0, device=dev)
+        vT = _new_cl((B,), C, H, W, y, _F32) if has_state else torch.empty(0, device=dev)
+        iT = _new_cl((B,), C, H, W, y, _F32) if has_state else torch.empty(0, device=dev)
         need_grad = any(ctx.needs_input_grad[:5])
         vdec = None
         ckpt = False
         if neuron in _SAVES_STEP and need_grad:
             # (the checkpointed kernels write / read all T outputs: not for the last-step-only read-out)
-            ckpt = (neuron == _hip.NEURON_LIF and LIF_CHECKPOINT_BYTES is not None and not last_only
+            ckpt = (neuron == _hip.NEURON_LIF and LIF_CHECKPOINT_BYTES is not None and not last_only and not sb
                     and T * M * C * 4 >= LIF_CHECKPOINT_BYTES)
             if ckpt:
                 k = _hip.query("snn_lif_ckpt_interval")
                 vdec = torch.empty(((T + k - 1) // k, 2, B, H, W, C), device=dev, dtype=_F32)
             else:
-                vdec = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
+                vdec = torch.empty((T, B, H, W, C), device=dev, dtype=y.dtype)
         if v0 is not None:
             v0 = _expand_state(v0, (B, C, H, W), dev)
         if i0 is not None:
@@ -954,6 +1023,8 @@ class _AffineNeuron(Function):
             addend = _raw_to_cl(addend)
             if tuple(addend.shape) != (T, B, C, H, W):
                 raise RuntimeError("Residual merge: branch outputs differ in shape")
+            if addend.dtype != y.dtype:
+                raise RuntimeError("Residual merge: shortcut and branch are stored in different types (fp32 / bf16)")
             ad_ptr, ld_ad = addend.data_ptr(), cl_stride(addend)
         if ckpt:
             _hip.call("snn_lif_fwd_ckpt", y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
@@ -963,8 +1034,9 @@ class _AffineNeuron(Function):
             _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
                       out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
                       _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params,
-                      _hip.SCAN_LAST_STEP_ONLY if last_only else 0, st)
+                      (_hip.SCAN_LAST_STEP_ONLY if last_only else 0) | sb_flag, st)
         ctx.ckpt = ckpt
+        ctx.sb = sb
         ctx.defer_apply = defer_apply
         ctx.last_only = last_only
         ctx.cfg = (neuron, has_bn, use_running, params, (T, B, C, H, W))
@@ -979,6 +1051,8 @@ class _AffineNeuron(Function):
         if not has_state:
             ctx.mark_non_differentiable(vT, iT)
         # with a neuron, vT / iT stay differentiable (time-outer BPTT through the carried state)
+        if sb and last_only:
+            out = out.float()   # the read-out of the last step (a few frames) leaves the bf16 domain here
         return out, vT, iT
 
     @staticmethod
@@ -994,11 +1068,15 @@ class _AffineNeuron(Function):
             g_addend = g_out
             if ctx.addend_acc is not None:  # lets the shortcut's producer-side dgrad add it in its epilogue
                 ctx.addend_acc[0].deposit(ctx.addend_acc[1], g_out)
+        sb = ctx.sb
         if g_out is None:
-            g_out = torch.zeros((B, H, W, C) if ctx.last_only else (T, B, H, W, C), device=dev, dtype=_F32)
+            g_out = torch.zeros((B, H, W, C) if ctx.last_only else (T, B, H, W, C), device=dev, dtype=y.dtype)
             g_out = _cl_view(g_out)
+        if g_out.dtype != y.dtype:
+            g_out = g_out.to(y.dtype)   # (bf16 storage: the fp32 gradient of the last-step read-out)
         g_out = _raw_to_cl(g_out)
-        scan_flags = SCAN_FLAGS | (_hip.SCAN_LAST_STEP_ONLY if ctx.last_only else 0)
+        es = y.element_size()
+        scan_flags = SCAN_FLAGS | (_hip.SCAN_LAST_STEP_ONLY if ctx.last_only else 0) | (_hip.SCAN_BF16_STORAGE if sb else 0)
         ldg, ldy = cl_stride(g_out), cl_stride(y)
         if not has_state:
             g_vT = g_iT = None
@@ -1010,9 +1088,9 @@ class _AffineNeuron(Function):
         need_gamma = has_bn and gamma is not None and ctx.needs_input_grad[1]
         need_bias = has_bn and ctx.needs_input_grad[2]
         need_sums = has_bn and ((need_y and not use_running) or need_gamma or need_bias)
-        gx = torch.empty((T, B, H, W, C), device=dev, dtype=_F32)
-        g_v0 = _new_cl((B,), C, H, W, y) if (has_state and ctx.has_v0 and ctx.needs_input_grad[3]) else None
-        g_i0 = _new_cl((B,), C, H, W, y) if (has_state and ctx.has_i0 and ctx.needs_input_grad[4]) else None
+        gx = torch.empty((T, B, H, W, C), device=dev, dtype=y.dtype)
+        g_v0 = _new_cl((B,), C, H, W, y, _F32) if (has_state and ctx.has_v0 and ctx.needs_input_grad[3]) else None
+        g_i0 = _new_cl((B,), C, H, W, y, _F32) if (has_state and ctx.has_i0 and ctx.needs_input_grad[4]) else None
         sums = None
         if need_sums:
             n_sums = _hip.query("snn_affine_neuron_bwd_sums_size", T, M, C)
@@ -1046,7 +1124,7 @@ class _AffineNeuron(Function):
         segmented = (need_sums and has_state and not ctx.ckpt and ctx.sync_group is None and SCAN_SEGMENT_T
                      and T > SCAN_SEGMENT_T)
         if segmented:
-            fr_g, fr_y, fr_c = M * ldg * 4, M * ldy * 4, M * C * 4    # bytes per timestep of g_out / y / dense tensors
+            fr_g, fr_y, fr_c = M * ldg * es, M * ldy * es, M * C * es    # bytes per timestep of g_out / y / dense tensors
             gv_in, gi_in = g_vT, g_iT
             first = True
             g_none = None   # last_only: the output gradient of every segment but the last one is zero
@@ -1110,8 +1188,8 @@ class _AffineNeuron(Function):
                 _PENDING_APPLY[gx.data_ptr()] = PendingBnApply(gx, y, coef, (T, B, C, H, W))
             elif need_y and not use_running:
                 # in place: dy overwrites gx
-                _hip.call("snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), ldy, coef[0].data_ptr(),
-                          coef[1].data_ptr(), coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
+                _hip.call("snn_bn_bwd_apply_bf16" if sb else "snn_bn_bwd_apply", gx.data_ptr(), y.data_ptr(), ldy,
+                          coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), gx.data_ptr(), C, T, M, C, 0, st)
         if need_y:
             dy = _cl_view(gx)
         return dy, dgamma, dbias, g_v0, g_i0, g_addend, None
@@ -1136,6 +1214,13 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     T-1 outputs are never written and the backward pass reads no output gradient for them.
     Returns ``(out, NeuronState | None)``.
     """
+    if y.dtype == _BF16 and (neuron not in (_hip.NEURON_NONE, _hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH)
+                             or y.shape[-3] % 4):
+        # no bf16-storage form of this scan (SLI / Synapse, channel counts that are not a multiple of 4): see _through_fp32
+        out, new_state = affine_neuron(y.float(), neuron, state, bn, params, None, None if addend is None else addend.float(),
+                                       last_only)
+        out = out if (last_only and y.dim() == 5) else out.to(_BF16)
+        return (place(out, dest) if dest is not None else out), new_state
     bn_hint = getattr(y, "_snn_bn_partial", None)
     defer_apply = bool(getattr(y, "_snn_defer_apply", False))
     seq, single = as_sequence(y)
@@ -1183,6 +1268,29 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
 
 
 # ------------------------------------------------------------------------------------------- merges
+def _copy_cl(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst = src, both (possibly channel-sliced) channels-last ``[T,B,C,H,W]``."""
+    if src.dtype != dst.dtype:
+        raise RuntimeError("merge: operands are stored in different types (fp32 / bf16 storage mixed)")
+    if src.dtype == _BF16:   # bf16 storage: copying merges are off the hot path (the Dense merge is zero-copy) - torch's copy
+        dst.copy_(src)
+        return
+    T, B, C, H, W = _dims5(src)
+    _hip.call("snn_copy_channels", src.data_ptr(), cl_stride(src), dst.data_ptr(), cl_stride(dst), T * B * H * W, C, _stream())
+
+
+def _add_cl(a: torch.Tensor, b: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst = a + b over channels-last ``[T,B,C,H,W]`` operands with their own pixel strides (dst may be a)."""
+    if not (a.dtype == b.dtype == dst.dtype):
+        raise RuntimeError("merge: operands are stored in different types (fp32 / bf16 storage mixed)")
+    if a.dtype == _BF16:     # bf16 storage: one rounding of the fp32 sum (torch's elementwise add)
+        torch.add(a, b, out=dst)
+        return
+    T, B, C, H, W = _dims5(a)
+    _hip.call("snn_add", a.data_ptr(), cl_stride(a), b.data_ptr(), cl_stride(b), dst.data_ptr(), cl_stride(dst),
+              T * B * H * W, C, _stream())
+
+
 class _Concat(Function):
     """Dense merge: torch.cat(out, dim=1) per timestep (generator.py:157-158), copying form."""
 
@@ -1193,13 +1301,12 @@ class _Concat(Function):
         widths = [x.shape[2] for x in xs]
         Ct = sum(widths)
         out = _out_tensor(dest, T, B, Ct, H, W, xs[0])
-        ldo = cl_stride(out)
-        M, st, off = T * B * H * W, _stream(), 0
+        off = 0
         for x, c in zip(xs, widths):
-            _require_device(x, "concat input")
+            _require_device(x, "concat input", bf16_ok=True)
             if x.shape[0] != T or x.shape[1] != B or x.shape[3] != H or x.shape[4] != W:
                 raise RuntimeError("Dense merge: branch outputs differ in shape")
-            _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr() + 4 * off, ldo, M, c, st)
+            _copy_cl(x, out.narrow(2, off, c))
             off += c
         ctx.widths = widths
         return out
@@ -1246,17 +1353,15 @@ class _Sum(Function):
     def forward(ctx, dest, *xs):
         xs = [_raw_to_cl(x) for x in xs]
         for x in xs:
-            _require_device(x, "residual input")
+            _require_device(x, "residual input", bf16_ok=True)
             if x.shape != xs[0].shape:
                 raise RuntimeError("Residual merge: branch outputs differ in shape")
         T, B, C, H, W = _dims5(xs[0])
         ctx.accs = [_acc_of(x) for x in xs]
         out = _out_tensor(dest, T, B, C, H, W, xs[0])
-        ldo, M, st = cl_stride(out), T * B * H * W, _stream()
-        _hip.call("snn_add", xs[0].data_ptr(), cl_stride(xs[0]), xs[1].data_ptr(), cl_stride(xs[1]), out.data_ptr(),
-                  ldo, M, C, st)
+        _add_cl(xs[0], xs[1], out)
         for x in xs[2:]:
-            _hip.call("snn_add", out.data_ptr(), ldo, x.data_ptr(), cl_stride(x), out.data_ptr(), ldo, M, C, st)
+            _add_cl(out, x, out)
         return out
 
     @staticmethod
@@ -1301,9 +1406,10 @@ class _Fanout(Function):
                                            "not expect (the alias was consumed more than once)")
                     continue
                 gk = _raw_to_cl(g)
-                T, B, C, H, W = _dims5(total)
-                _hip.call("snn_add", total.data_ptr(), C, gk.data_ptr(), cl_stride(gk), total.data_ptr(), C,
-                          T * B * H * W, C, _stream())
+                if total.dim() == 4:
+                    _add_cl(total.unsqueeze(0), gk.unsqueeze(0), total.unsqueeze(0))
+                else:
+                    _add_cl(total, gk, total)
         else:
             live = [g for g in gs if g is not None]
             if not live:
@@ -1315,11 +1421,9 @@ class _Fanout(Function):
                 seqs = [_raw_to_cl(g.unsqueeze(0) if single else g) for g in live]
                 T, B, C, H, W = _dims5(seqs[0])
                 out = _new_cl((T, B), C, H, W, seqs[0])
-                M, st = T * B * H * W, _stream()
-                _hip.call("snn_add", seqs[0].data_ptr(), cl_stride(seqs[0]), seqs[1].data_ptr(), cl_stride(seqs[1]),
-                          out.data_ptr(), C, M, C, st)
+                _add_cl(seqs[0], seqs[1], out)
                 for g in seqs[2:]:
-                    _hip.call("snn_add", out.data_ptr(), C, g.data_ptr(), cl_stride(g), out.data_ptr(), C, M, C, st)
+                    _add_cl(out, g, out)
                 total = out[0] if single else out
         acc.deposits.clear()
         acc.fused.clear()
@@ -1345,8 +1449,7 @@ class _Place(Function):
         x = _raw_to_cl(x)
         T, B, C, H, W = _dims5(x)
         out = dest.tensor(T, B, C, H, W, x)
-        _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr(), cl_stride(out), T * B * H * W, C,
-                  _stream())
+        _copy_cl(x, out)
         return out
 
     @staticmethod
@@ -1433,10 +1536,21 @@ class _Act(Function):
         return gx, None
 
 
+def _through_fp32(op, x: torch.Tensor, *args):
+    """Operators without a bf16-storage kernel (activations, pooling, up-sampling, ConvLSTM, SLI / Synapse: none of them is
+    on the TinyYolo path) still work in that mode: the tensor is widened to fp32 for the operator and its result is
+    narrowed again (two conversion passes - correct, not fast)."""
+    if x.dtype != _BF16:
+        return op(x, *args)
+    return op(x.float(), *args).to(_BF16)
+
+
 def activation(x: torch.Tensor, act: int) -> torch.Tensor:
-    seq, single = as_sequence(x)
-    y = _Act.apply(seq, act)
-    return y[0] if single else y
+    def run(t, a):
+        seq, single = as_sequence(t)
+        y = _Act.apply(seq, a)
+        return y[0] if single else y
+    return _through_fp32(run, x, act)
 
 
 class _Pool(Function):
@@ -1466,9 +1580,11 @@ class _Pool(Function):
 
 
 def pool2d(x: torch.Tensor, kind: int, kernel_size: int, stride: int) -> torch.Tensor:
-    seq, single = as_sequence(x)
-    y = _Pool.apply(seq, kind, int(kernel_size), int(stride))
-    return y[0] if single else y
+    def run(t, *a):
+        seq, single = as_sequence(t)
+        y = _Pool.apply(seq, *a)
+        return y[0] if single else y
+    return _through_fp32(run, x, kind, int(kernel_size), int(stride))
 
 
 class _Upsample(Function):
@@ -1492,9 +1608,11 @@ class _Upsample(Function):
 
 
 def upsample_nearest(x: torch.Tensor, scale: int) -> torch.Tensor:
-    seq, single = as_sequence(x)
-    y = _Upsample.apply(seq, int(scale))
-    return y[0] if single else y
+    def run(t, sc):
+        seq, single = as_sequence(t)
+        y = _Upsample.apply(seq, sc)
+        return y[0] if single else y
+    return _through_fp32(run, x, int(scale))
 
 
 # ------------------------------------------------------------------------------------------- ConvLSTM
@@ -1531,6 +1649,9 @@ class _LstmCell(Function):
 
 
 def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]):
+    if gates.dtype == _BF16:   # (see _through_fp32) the cell state c stays fp32 across the steps
+        h, c = _LstmCell.apply(gates.float(), None if c_prev is None else c_prev.float())
+        return h.to(_BF16), c
     return _LstmCell.apply(gates, c_prev)
 
 
@@ -1553,6 +1674,8 @@ class _StackTime(Function):
 
 
 def stack_time(xs: List[torch.Tensor]) -> torch.Tensor:
+    if xs and xs[0].dtype == _BF16:
+        return torch.stack(list(xs))   # (time-outer loops are off the layer-major path) torch's copy
     return _StackTime.apply(*xs)
 
 

@@ -40,24 +40,40 @@ def _conv_label(name: str, a) -> str:
     return f"k_conv_gather<{tile}, {'true' if dgrad else 'false'}, {'true' if ic % 4 == 0 else 'false'}>"
 
 
+PREC_BF16S, SCAN_BF16_STORAGE = 6, 4   # include/snn_hip.h: the bf16-storage mode (activation tensors 2 bytes per element)
+
+
 def work_of(name: str, a):
-    """-> (label, flops, bytes) for one launch, or (name, 0, 0) for bookkeeping kernels."""
+    """-> (label, flops, bytes) for one launch, or (name, 0, 0) for bookkeeping kernels.  Activation tensors count 4 bytes
+    per element, or 2 in the bf16-storage mode (labels carry "bf16s" then); weights and weight gradients are fp32."""
     if name in ("snn_conv2d_fwd", "snn_conv2d_dgrad"):
         a = tuple(a[:3]) + tuple(a[4:])   # without the pre-split weight pointer: the positions snn_conv2d_wgrad has
         n, h, w, cin, ho, wo, cout, kh, kw = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]
+        sb = a[21 if name == "snn_conv2d_fwd" else 20] == PREC_BF16S
+        es = 2.0 if sb else 4.0
+        es_in = 4.0 if (cin == 2 and name == "snn_conv2d_fwd") else es   # the event frames stay fp32
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
-        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
-        return _conv_label(name, a), flops, byts
+        byts = es_in * n * h * w * cin + es * n * ho * wo * cout + 4.0 * cout * kh * kw * cin
+        label = _conv_label(name, a)
+        if sb and not label.startswith("k_conv_first"):   # bf16 storage: always the implicit GEMM (no direct-3x3 form)
+            oc = cin if name == "snn_conv2d_dgrad" else cout
+            label = (f"k_conv_gather<{'32, 4, 1' if oc <= 32 else ('64, 2, 2' if oc <= 64 else '128, 2, 2')}, "
+                     f"{'true' if name == 'snn_conv2d_dgrad' else 'false'}, true>")
+        return label + (", bf16s" if sb else ""), flops, byts
     if name == "snn_conv2d_wgrad":
         n, h, w, cin, ho, wo, cout, kh, kw = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]
+        sb = a[19] == PREC_BF16S
+        es = 2.0 if sb else 4.0
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
-        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
-        return _conv_label(name, a), flops, byts
+        byts = (4.0 if cin == 2 else es) * n * h * w * cin + es * n * ho * wo * cout + 4.0 * cout * kh * kw * cin
+        return _conv_label(name, a) + (", bf16s" if sb else ""), flops, byts
     if name == "snn_conv3x3_halo":   # halo-resident 3x3 / stride 1 (csrc/conv_halo.hip): forward (fp16 x 3) or data gradient
         n, h, w, cin, cout, prec = a[5], a[6], a[7], a[8], a[9], a[17]
+        es = 2.0 if prec == PREC_BF16S else 4.0
         flops = 2.0 * n * h * w * cout * 9 * cin
-        byts = 4.0 * (n * h * w * cin + n * h * w * cout + cout * 9 * cin)
-        return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, {'fwd' if prec == 4 else 'dgrad'}>", flops, byts
+        byts = es * (n * h * w * cin + n * h * w * cout) + 4.0 * cout * 9 * cin
+        kind = "fwd" if prec == 4 else ("dgrad" if prec == 1 else "bf16s")   # (bf16 storage: one instance serves both)
+        return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, {kind}>", flops, byts
     if name == "snn_conv3x3_halo_bn":   # the same data gradient with the BatchNorm-backward affine applied while staging
         n, h, w, cin, cout = a[8], a[9], a[10], a[11], a[12]
         flops = 2.0 * n * h * w * cout * 9 * cin
@@ -65,9 +81,10 @@ def work_of(name: str, a):
         return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, dgrad>", flops, byts
     if name == "snn_conv3x3_s2_dgrad":   # one-pass stride-2 data gradient
         n, h, w, cin, ho, wo, cout = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        sb = a[16] == PREC_BF16S
         flops = 2.0 * n * ho * wo * cout * 9 * cin
-        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * 9 * cin)
-        return "k_conv_s2dgrad3<dgrad>", flops, byts
+        byts = (2.0 if sb else 4.0) * (n * h * w * cin + n * ho * wo * cout) + 4.0 * cout * 9 * cin
+        return "k_conv_s2dgrad3<dgrad>" + (", bf16s" if sb else ""), flops, byts
     if name == "snn_conv2d_wgrad_bn":   # event-frame weight gradient with the BatchNorm-backward affine applied on the fly
         n, h, w, cin, ho, wo, cout, kh, kw = a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18]
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
@@ -79,7 +96,8 @@ def work_of(name: str, a):
         elems = float(T) * M * C
         # y read; out written (one step of it with last_only); + vdec, + fused shortcut
         tensors = 1 + (1.0 / T if last_only else 1) + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)
-        return f"k_affine_neuron_fwd<{neuron}>", 12.0 * elems, 4.0 * elems * tensors
+        sb = bool(a[18] & SCAN_BF16_STORAGE)
+        return f"k_affine_neuron_fwd<{neuron}>" + (", bf16s" if sb else ""), 12.0 * elems, (2.0 if sb else 4.0) * elems * tensors
     if name == "snn_affine_neuron_bwd":
         neuron, T, M, C = a[0], a[15], a[16], a[17]
         last_only = bool(a[19] & 2)   # output gradient (and a saved OUTPUT, LI+Tanh) exist for the last step only
@@ -87,7 +105,8 @@ def work_of(name: str, a):
         one = 1.0 / T if last_only else 1
         saved = 0 if a[3] is None else (one if neuron == 3 else 1)   # LIF & co. save v_dec per step, LI+Tanh its output
         tensors = one + 1 + saved + (1 if a[14] is not None else 0)   # g_out, gx, saved state, y (for the BN sums)
-        return f"k_affine_neuron_bwd<{neuron}>", 16.0 * elems, 4.0 * elems * tensors
+        sb = bool(a[19] & SCAN_BF16_STORAGE)
+        return f"k_affine_neuron_bwd<{neuron}>" + (", bf16s" if sb else ""), 16.0 * elems, (2.0 if sb else 4.0) * elems * tensors
     if name == "snn_lif_fwd_ckpt":  # y, out (+ shortcut), checkpoints = 2/K of a tensor
         T, M, C = a[13], a[14], a[15]
         elems = float(T) * M * C
@@ -96,12 +115,14 @@ def work_of(name: str, a):
         T, M, C = a[14], a[15], a[16]
         elems = float(T) * M * C
         return "k_lif_bwd_ckpt", 28.0 * elems, 4.0 * elems * 3.5
-    if name == "snn_bn_stats":
+    if name in ("snn_bn_stats", "snn_bn_stats_bf16"):
         T, M, C = a[2], a[3], a[4]
-        return "k_bn_stats", 3.0 * T * M * C, 4.0 * T * M * C
-    if name == "snn_bn_bwd_apply":
+        sb = name.endswith("_bf16")
+        return "k_bn_stats" + (", bf16s" if sb else ""), 3.0 * T * M * C, (2.0 if sb else 4.0) * T * M * C
+    if name in ("snn_bn_bwd_apply", "snn_bn_bwd_apply_bf16"):
         T, M, C = a[8], a[9], a[10]
-        return "k_bn_bwd_apply", 4.0 * T * M * C, 12.0 * T * M * C
+        sb = name.endswith("_bf16")
+        return "k_bn_bwd_apply" + (", bf16s" if sb else ""), 4.0 * T * M * C, (6.0 if sb else 12.0) * T * M * C
     if name in ("snn_copy_channels", "snn_add_channels"):
         M, C = a[4], a[5]
         return "k_channels", 0.0, (8.0 if name == "snn_copy_channels" else 12.0) * M * C

@@ -122,6 +122,7 @@ class FlatTrainer:
             self._frag_tables = (torch.tensor(fwd_rows, dtype=torch.int64, device=dev),
                                  torch.tensor(bwd_rows, dtype=torch.int64, device=dev),
                                  max(9 * (i // 32) * (o // 32) * 128 for _, _, o, i in frag_table))
+            self._frag_params = [p for p, _, _, _ in frag_table]
             for p, f_off, o, i in frag_table:
                 p._snn_wfrag = self.flat_wfrag[f_off:f_off + p.numel()]
                 p._snn_wtfrag = self.flat_wtfrag[f_off:f_off + p.numel()]
@@ -202,8 +203,12 @@ class FlatTrainer:
             _hip.call("snn_weight_presplit", self.flat_wt.data_ptr(), self.flat_wt16.data_ptr(), n, _hip.PREC_BF16X3, st)
         if self._frag_tables is not None:
             fwd_t, bwd_t, max_threads = self._frag_tables
+            # forward image: fp16 pieces (fp16 x 3), or bf16 pieces when the activations are stored in bf16
+            fwd_prec = _hip.PREC_BF16X3 if _HF.get_activation_storage() == "bf16" else _hip.PREC_FP16X3
             _hip.call("snn_weight_frag_image_batched", self.flat_param.data_ptr(), self.flat_wfrag.data_ptr(),
-                      fwd_t.data_ptr(), fwd_t.shape[0], max_threads, 0, _hip.PREC_FP16X3, st)
+                      fwd_t.data_ptr(), fwd_t.shape[0], max_threads, 0, fwd_prec, st)
+            for p in self._frag_params:
+                p._snn_wfrag_prec = fwd_prec
             _hip.call("snn_weight_frag_image_batched", self.flat_wt.data_ptr(), self.flat_wtfrag.data_ptr(),
                       bwd_t.data_ptr(), bwd_t.shape[0], max_threads, 1, _hip.PREC_BF16X3, st)
         for p in self._conv_params:

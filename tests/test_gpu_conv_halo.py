@@ -257,7 +257,7 @@ def test_one_pass_stride2_data_gradient_against_fp64(H_, N, H, W, Cin, Cout):
     a1 = torch.randn(N, H, W, Cin, device="cuda")
     dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
     _hip.call("snn_conv3x3_s2_dgrad", gyd.data_ptr(), Cout, img_t.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
-              None, 0, None, 0, st)
+              None, 0, None, 0, _hip.PREC_BF16X3, st)
     assert torch.isfinite(dx).all()                                   # every dx pixel of every class was written
     assert rel_err(dx, dx_ref) < 3e-5
     # the four-launch implicit GEMM computes the same products
@@ -268,7 +268,7 @@ def test_one_pass_stride2_data_gradient_against_fp64(H_, N, H, W, Cin, Cout):
     # fused addend, determinism
     dx2 = torch.empty_like(dx)
     _hip.call("snn_conv3x3_s2_dgrad", gyd.data_ptr(), Cout, img_t.data_ptr(), dx2.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
-              a1.data_ptr(), Cin, None, 0, st)
+              a1.data_ptr(), Cin, None, 0, _hip.PREC_BF16X3, st)
     assert torch.equal(dx2, dx + a1)
 
 

@@ -97,7 +97,7 @@ def stride2():
             "dgrad 4-pass": lambda: _hip.call("snn_conv2d_dgrad", dy.data_ptr(), Cout, wt.data_ptr(), None, dx.data_ptr(), Cin, N,
                                               H, W, Cin, Ho, Wo, Cout, 3, 3, 2, 1, None, 0, None, 0, 1, st),
             "dgrad 1-pass": lambda: _hip.call("snn_conv3x3_s2_dgrad", dy.data_ptr(), Cout, img.data_ptr(), dx.data_ptr(), Cin, N,
-                                              H, W, Cin, Ho, Wo, Cout, None, 0, None, 0, st),
+                                              H, W, Cin, Ho, Wo, Cout, None, 0, None, 0, 1, st),
         }
         t0 = time.time()
         while time.time() - t0 < 1.0:
