@@ -484,6 +484,9 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 #define SNN_BWD_NP 4
 #endif
 constexpr int kBwdNP = SNN_BWD_NP;
+#ifndef SNN_BWD_SB_DEPTH
+#define SNN_BWD_SB_DEPTH 3   // operand sets in flight in the bf16-storage reverse scan (2 or 3)
+#endif
 constexpr int kWaves = kThreads / 64;
 
 struct BwdPlan {
@@ -494,31 +497,12 @@ struct BwdPlan {
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-static BwdPlan bwd_plan_lds(int T, int64_t M, int C, bool with_sums, int lds_kib);
-
-// The per-wave sum slabs of a block take up to `budget` KiB of LDS, which decides how many blocks a CU holds (64 KiB: 2)
-// and how many channels a block covers.  On the large maps that is the right trade (long pixel runs per block, wide
-// channel runs per pixel).  On the mid-size maps (30x38 x 128..256 channels at B = 5) the 2-per-CU grid is not even full:
-// ~350 blocks whose threads each walk 2 pixel rows x T steps - a serial VALU chain (the masked rows of the NP-row
-// groups compute too) that ran 81 us where the same scan without sums takes 28.  A smaller slab (fewer channels per
-// block, more blocks per CU, one pixel row per thread) shortens the chain; taken only while the plan leaves CUs idle.
+// (Measured and rejected: a smaller slab budget - 32 / 16 KiB, more blocks of fewer channels - for the mid-size maps whose
+// 64 KiB plan leaves CUs idle.  The 30x38 x 128-channel scan alone went 81 -> 59 us in isolation, but inside the step the
+// family average rose from 98 to 125 us (bf16 storage) and 147 to 151 us (fp32): narrower channel runs per pixel and a
+// second round of blocks on the small maps cost more than the shorter serial chains gain.)
 static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
-    BwdPlan best = bwd_plan_lds(T, M, C, with_sums, 64);
-    if (!with_sums || snn_tuning_env("SNN_BWD_LDS64")) return best;
-    for (int kib = 32; kib >= 16; kib /= 2) {
-        const int64_t blocks = (int64_t)best.gx * best.gy;
-        if (blocks >= 2 * (int64_t)snn_num_cu()) break;                      // two blocks per CU: the chip is full
-        // (also tried: the smaller slab whenever the NP-row groups are partly masked - the large maps then run several
-        // rounds of blocks and lose 2x)
-        BwdPlan alt = bwd_plan_lds(T, M, C, with_sums, kib);
-        if (alt.cvb * alt.vec * 4 < 64 && alt.gy > best.gy) break;           // keep >= 64-byte channel runs per pixel (fp32 size)
-        if ((int64_t)alt.gx * alt.gy <= blocks) break;
-        best = alt;
-    }
-    return best;
-}
-
-static BwdPlan bwd_plan_lds(int T, int64_t M, int C, bool with_sums, int lds_kib) {
+    constexpr int lds_kib = 64;
     BwdPlan pl;
     pl.vec = (C % 4 == 0) ? 4 : 1;
     int cv = C / pl.vec;
@@ -639,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
         // half the registers, which pays for a THIRD set: with half the bytes per step, one step of prefetch no longer
         // covers the memory latency (3.0 - 4.5 TB/s measured with two sets against 5 TB/s on fp32 tensors).
         using R = typename std::conditional<(SB && BUF), snn_u32x2, V>::type;
-        constexpr int DEPTH = (SB && BUF) ? 3 : 2;
+        constexpr int DEPTH = (SB && BUF) ? SNN_BWD_SB_DEPTH : 2;
         auto widen = [](const R& r) -> V {
             if constexpr (SB && BUF) return snn_unpack_bf16x4(r);
             else return r;
@@ -648,8 +632,16 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             if constexpr (SB && BUF) return __builtin_bit_cast(snn_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
             else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         };
-        auto fetch = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP]) {
+        // eval-mode BatchNorm scale alpha[t][c] (apply_scale): fetched with the operand set - a load inside a branch of the
+        // time loop makes the compiler's wait-count pass fall back to small vmcnt values for the whole step (it cannot
+        // know whether the load was issued), which stalls on the prefetched set.  Zero records when unused.
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rsc;
+        if constexpr (BUF)
+            rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(apply_scale ? alpha : g_out), 0,
+                                                    apply_scale ? (int)((int64_t)T * C * 4) : 0, 0x00020000);
+        auto fetch = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP], V& sc) {
             if constexpr (BUF) {
+                sc = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rsc, lane_ok ? (t * C + c) * 4 : -1, 0, 0));
                 const __amdgpu_buffer_rsrc_t rg = slab_out(g_out, t, ldg);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
@@ -685,7 +677,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 }
             }
         };
-        auto process = [&](int t, R (&go_r)[NP], R (&st_r)[NP], R (&yv_r)[NP]) {
+        auto process = [&](int t, R (&go_r)[NP], R (&st_r)[NP], R (&yv_r)[NP], const V& sc_set) {
             float s1[VEC], s2[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.0f;
@@ -773,7 +765,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     }
                 }
                 if (apply_scale) {
-                    V sc = Vec<VEC>::load(alpha + (int64_t)t * C + c);
+                    V sc = sc_set;
+                    if constexpr (!BUF) sc = Vec<VEC>::load(alpha + (int64_t)t * C + c);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) lane<VEC>(g, j) = lane<VEC>(g, j) * lane<VEC>(sc, j);
                 }
@@ -818,32 +811,45 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             }
                 };
         R goA[NP], stA[NP], yvA[NP], goB[NP], stB[NP], yvB[NP];
+        V scA, scB;
+        // steps below 0 re-read step 0: no branch around the loads of the BUF form (see the note on `rsc`)
+        auto fetch0 = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP], V& sc) { fetch(t > 0 ? t : 0, go, st, yv, sc); };
         if constexpr (DEPTH == 3) {
-            // three sets, two steps ahead; steps below 0 re-read step 0 (no branch around the loads)
+            // three sets, two steps ahead
             R goC[NP], stC[NP], yvC[NP];
-            auto fetch0 = [&](int t, R (&go)[NP], R (&st)[NP], R (&yv)[NP]) { fetch(t > 0 ? t : 0, go, st, yv); };
-            fetch(T - 1, goA, stA, yvA);
-            fetch0(T - 2, goB, stB, yvB);
+            V scC;
+            fetch(T - 1, goA, stA, yvA, scA);
+            fetch0(T - 2, goB, stB, yvB, scB);
             for (int t = T - 1; t >= 0; t -= 3) {
-                fetch0(t - 2, goC, stC, yvC);
-                process(t, goA, stA, yvA);
+                fetch0(t - 2, goC, stC, yvC, scC);
+                process(t, goA, stA, yvA, scA);
                 if (t >= 1) {
-                    fetch0(t - 3, goA, stA, yvA);
-                    process(t - 1, goB, stB, yvB);
+                    fetch0(t - 3, goA, stA, yvA, scA);
+                    process(t - 1, goB, stB, yvB, scB);
                 }
                 if (t >= 2) {
-                    fetch0(t - 4, goB, stB, yvB);
-                    process(t - 2, goC, stC, yvC);
+                    fetch0(t - 4, goB, stB, yvB, scB);
+                    process(t - 2, goC, stC, yvC, scC);
+                }
+            }
+        } else if constexpr (BUF) {
+            fetch(T - 1, goA, stA, yvA, scA);
+            for (int t = T - 1; t >= 0; t -= 2) {
+                fetch0(t - 1, goB, stB, yvB, scB);
+                process(t, goA, stA, yvA, scA);
+                if (t >= 1) {
+                    fetch0(t - 2, goA, stA, yvA, scA);
+                    process(t - 1, goB, stB, yvB, scB);
                 }
             }
         } else {
-            fetch(T - 1, goA, stA, yvA);
+            fetch(T - 1, goA, stA, yvA, scA);
             for (int t = T - 1; t >= 0; t -= 2) {
-                if (t >= 1) fetch(t - 1, goB, stB, yvB);
-                process(t, goA, stA, yvA);
+                if (t >= 1) fetch(t - 1, goB, stB, yvB, scB);
+                process(t, goA, stA, yvA, scA);
                 if (t >= 1) {
-                    if (t >= 2) fetch(t - 2, goA, stA, yvA);
-                    process(t - 1, goB, stB, yvB);
+                    if (t >= 2) fetch(t - 2, goA, stA, yvA, scA);
+                    process(t - 1, goB, stB, yvB, scB);
                 }
             }
         }
