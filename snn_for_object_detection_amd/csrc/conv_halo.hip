@@ -127,7 +127,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                                                            const float* __restrict__ bn_y = nullptr,
                                                            const float* __restrict__ bn_coef = nullptr,
                                                            float* __restrict__ dy_out = nullptr) {
-    constexpr int WM = 2, WN = 2, TM = 2, TN = CO / 64;
+    // CO = 32 (the 32-channel layers of the full-resolution stage): the four waves side by side along the cells, one
+    // 32 x 32 tile each
+    constexpr int WM = CO == 32 ? 4 : 2, WN = 4 / WM, TM = CO == 32 ? 1 : 2, TN = CO == 32 ? 1 : CO / 64;
+    static_assert(CO == 32 || CO == 64 || CO == 128, "channel tile");
+    static_assert(!BNAP || CO >= 64, "the BatchNorm-apply variant covers the 64 / 128-channel tiles");
     constexpr int BTILE = (CO / 32) * 4096;     // bytes of one k-step's weight tile
     constexpr int NDMA = (CO / 32) * 4 / 4;     // 1-KiB LDS-DMA pieces per wave and k-step
     constexpr int ES = SBF ? 2 : 4;             // bytes per activation element in HBM
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
     // XCD-aware order: ids b, b + 8, ... share an XCD (its own L2); XCD q walks the q-th contiguous run of tiles, so
@@ -805,7 +809,8 @@ static bool out_aligned(const void* p, bool bf16) { return bf16 ? aligned8(p) : 
 // 0: not covered, 1: padded-strip tiles (rows of <= 78 pixels), 2: 4 x 32 rectangles (any width)
 static int halo_mode(int64_t N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    if (Cin % 32 != 0 || Cin < 32 || Cout % 64 != 0) return 0;
+    if (Cin % 32 != 0 || Cin < 32 || (Cout % 64 != 0 && Cout != 32)) return 0;
+    if (Cout == 32 && snn_tuning_env("SNN_HALO_NO_CO32")) return 0;   // tuning / bisecting aid
     if (W + 1 <= 79) {                                              // halo of a 128-cell tile: 128 + 2*PW + 2 <= 288 cells
         if (N * (int64_t)(H + 1) * (W + 1) >= 0x7fffffffLL) return 0;   // strip cells of a group in 32 bits
         return 1;
@@ -1009,7 +1014,7 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
         g.tiles_per_group = (int)snn_ceil_div(group_cells, HBM_);
         tiles = (int64_t)(N / g.G) * g.tiles_per_group;
     }
-    const int co_tile = Cout % 128 == 0 ? 128 : 64;
+    const int co_tile = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
     g.ntiles_n = Cout / co_tile;
     SNN_REQUIRE(tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_halo: grid too large");
     g.tiles = (int)tiles;
@@ -1056,15 +1061,19 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
             hipLaunchKernelGGL((k_conv_halo3<CO_, false, 0, false, false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, \
                                x, wi, y, g, addend, addend2, nullptr, nullptr, nullptr);                              \
     } while (0)
-        if (co_tile == 128) SNN_HALO_LAUNCH_S(128); else SNN_HALO_LAUNCH_S(64);
+        if (co_tile == 128) SNN_HALO_LAUNCH_S(128);
+        else if (co_tile == 64) SNN_HALO_LAUNCH_S(64);
+        else SNN_HALO_LAUNCH_S(32);
 #undef SNN_HALO_LAUNCH_S
         SNN_CHECK_LAUNCH("snn_conv3x3_halo");
         return 0;
     }
     if (co_tile == 128) {
         if (f16) SNN_HALO_LAUNCH(128, true); else SNN_HALO_LAUNCH(128, false);
-    } else {
+    } else if (co_tile == 64) {
         if (f16) SNN_HALO_LAUNCH(64, true); else SNN_HALO_LAUNCH(64, false);
+    } else {
+        if (f16) SNN_HALO_LAUNCH(32, true); else SNN_HALO_LAUNCH(32, false);
     }
 #undef SNN_HALO_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv3x3_halo");

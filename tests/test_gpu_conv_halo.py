@@ -46,6 +46,10 @@ HALO_CASES = [
     (1, 7, 304, 64, 128),     # the deep-backbone row length, partial rectangles on the bottom edge (7 = 4 + 3)
     (3, 33, 81, 32, 64),      # one chunk, 81 = 2 * 32 + 17
     (2, 90, 160, 128, 128),   # a 1 Mpx neck map
+    # 32 output channels: four waves side by side along the cells (the full-resolution stage)
+    (2, 40, 52, 32, 32),      # strip tiles
+    (2, 21, 152, 32, 32),     # rectangles, partial on both edges
+    (3, 9, 30, 64, 32),       # two chunks into one 32-channel tile (data gradient: 32 -> 64)
 ]
 
 
@@ -123,7 +127,8 @@ def test_halo_channel_slices_and_fused_addends(H_):
 
 @pytest.mark.parametrize("T,B,H,W,Cin,Cout", [(3, 2, 30, 38, 64, 64), (4, 3, 15, 19, 128, 128), (5, 1, 8, 10, 64, 128),
                                              (2, 5, 60, 76, 64, 64), (6, 2, 3, 4, 32, 64),
-                                             (3, 2, 13, 100, 64, 64), (2, 1, 21, 304, 64, 64)])   # the last two: RECT tiles
+                                             (3, 2, 13, 100, 64, 64), (2, 1, 21, 304, 64, 64),    # these two: RECT tiles
+                                             (3, 2, 20, 26, 32, 32), (2, 2, 9, 90, 32, 32)])      # the 32-channel tile
 def test_halo_batchnorm_statistics_partials(H_, T, B, H, W, Cin, Cout):
     """The partials the forward leaves for the BatchNorm behind it (per timestep, tiles never straddle two steps) give
     the sums of the stored values - against fp64 sums of y and against the separate statistics pass."""
@@ -173,10 +178,11 @@ def test_halo_refuses_uncovered_shapes(H_):
     x = torch.zeros(1, 4, 100, 64, device="cuda")
     img = torch.zeros(9 * 64 * 64, device="cuda")
     y = torch.zeros(1, 4, 100, 64, device="cuda")
-    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 32) == 0          # 32 output channels: the direct kernel
+    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 96) == 0          # channel tiles: 32, or multiples of 64
+    assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 64, 32) == 1
     assert _hip.query("snn_conv3x3_halo_supported", 1, 4, 100, 48, 64) == 0          # input channels not a multiple of 32
     with pytest.raises(RuntimeError, match="shape not covered"):
-        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 100, 64, 32, None, 0, None, 0,
+        _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 100, 64, 96, None, 0, None, 0,
                   None, 0, None, _hip.PREC_FP16X3, st)
     with pytest.raises(RuntimeError, match="precision"):
         _hip.call("snn_conv3x3_halo", x.data_ptr(), 64, img.data_ptr(), y.data_ptr(), 64, 1, 4, 50, 64, 64, None, 0, None, 0,

@@ -79,7 +79,8 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 128) == 1
     assert hip_lib.snn_conv3x3_halo_supported(160, 120, 152, 64, 64) == 1      # long rows: 4 x 32 rectangles
     assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 120, 152) == 5 * 30 * 5
-    assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 32) == 0       # <= 32 output channels: direct kernel
+    assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 32) == 1       # the 32-channel tile
+    assert hip_lib.snn_conv3x3_halo_supported(160, 30, 38, 128, 96) == 0       # channel tiles: 32, or multiples of 64
     assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) == (5 * 31 * 39 + 127) // 128
     assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 5, 30, 38, 128) >= 32 * hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) * 128 * 2
     assert hip_lib.snn_weight_frag_image_bytes(128, 64) == 9 * 128 * 64 * 4

@@ -24,7 +24,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--co32", action="store_true", help="the 32-channel full-resolution layer only (A = direct 3x3 kernel)")
     args = ap.parse_args()
+    if args.co32:
+        SHAPES[:] = [(160, 120, 152, 32, 32), (160, 60, 76, 32, 32)]
     _hip.load()
     dev = torch.device("cuda")
     st = torch.cuda.current_stream().cuda_stream
