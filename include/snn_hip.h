@@ -362,6 +362,13 @@ int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float*
  * the operand of its data gradient. */
 int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                   int64_t ldc, int M, int N, int K, int accumulate, float* Ct, int64_t ldct, void* stream);
+/* n products C_i = A_i B_i of dense row-major matrices (A_i [M,K], B_i [K,N], C_i [M,N]; Ct_i [N,M] = the transposed copy,
+ * base_ct may be NULL) in ONE launch: the composed 1x1 weights w2 w1 of every C2f entry (reference models/tiny_yolo.py:76-82)
+ * once per optimiser step.  `table` (device): n rows {A offset, B offset, C offset, Ct offset, M, N, K} as int64, offsets in
+ * floats relative to the four base pointers; max_tiles >= ceil(M/32) * ceil(N/32) of every row.  Same fmaf chains (k order)
+ * as snn_small_gemm. */
+int snn_small_gemm_batched(const float* base_a, const float* base_b, float* base_c, float* base_ct, const int64_t* table,
+                           int n, int max_tiles, void* stream);
 
 /* ConvLSTM cell (conv_lstm.py:51-78), pointwise part after the 1x1 gate convolution.  gates is dense
  * [M][4C] = (input, forget, output, candidate); c_prev NULL = zero state.

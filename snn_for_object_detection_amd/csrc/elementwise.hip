@@ -335,13 +335,11 @@ __global__ void k_events(const int32_t* __restrict__ tb, const int32_t* __restri
 // k order (same arithmetic as the fp32 MFMA).
 constexpr int GEMM_KC = 128;
 template <bool TA, bool TB>
-__global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict__ A, int64_t lda,
-                                                         const float* __restrict__ B, int64_t ldb,
-                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                         int accumulate, float* __restrict__ Ct, int64_t ldct) {
+__device__ __forceinline__ void small_gemm_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                int accumulate, float* __restrict__ Ct, int64_t ldct, int m0, int n0) {
     __shared__ float As[GEMM_KC][33], Bs[GEMM_KC][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
         float ra[GEMM_KC * 32 / kThreads], rb[GEMM_KC * 32 / kThreads];
@@ -382,6 +380,30 @@ __global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict
                 if (Ct) Ct[(int64_t)n * ldct + m] = acc[i][j];   // the transposed copy (weight-sized: strided stores are fine)
             }
         }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                         int accumulate, float* __restrict__ Ct, int64_t ldct) {
+    small_gemm_tile<TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct, blockIdx.y * 32, blockIdx.x * 32);
+}
+
+// n independent products C_i = A_i B_i (+ the transposed copy) in one launch: table row {A offset, B offset, C offset, Ct
+// offset, M, N, K} in floats relative to base_a / base_b / base_c / base_ct; blockIdx.y = the product, blockIdx.x = its tile
+// (blocks past a product's last tile leave at once).  Dense row-major operands.
+__global__ __launch_bounds__(kThreads) void k_small_gemm_batched(const float* __restrict__ base_a,
+                                                                 const float* __restrict__ base_b,
+                                                                 float* __restrict__ base_c, float* __restrict__ base_ct,
+                                                                 const int64_t* __restrict__ table) {
+    const int64_t* row = table + (int64_t)blockIdx.y * 7;
+    const int M = (int)row[4], N = (int)row[5], K = (int)row[6];
+    const int tn = (N + 31) / 32, tm = (M + 31) / 32;
+    if ((int)blockIdx.x >= tn * tm) return;   // whole block, before any barrier
+    small_gemm_tile<false, false>(base_a + row[0], K, base_b + row[1], N, base_c + row[2], N, M, N, K, 0,
+                                  base_ct ? base_ct + row[3] : nullptr, M, ((int)blockIdx.x / tn) * 32,
+                                  ((int)blockIdx.x % tn) * 32);
 }
 
 }  // namespace
@@ -499,6 +521,16 @@ extern "C" int snn_small_gemm(const float* A, int64_t lda, int transA, const flo
     else if (transB) hipLaunchKernelGGL((k_small_gemm<false, true>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
     else hipLaunchKernelGGL((k_small_gemm<false, false>), grid, dim3(kThreads), 0, st, A, lda, B, ldb, C, ldc, M, N, K, accumulate, Ct, ldct);
     SNN_CHECK_LAUNCH("snn_small_gemm");
+    return 0;
+}
+
+extern "C" int snn_small_gemm_batched(const float* base_a, const float* base_b, float* base_c, float* base_ct,
+                                      const int64_t* table, int n, int max_tiles, void* stream) {
+    SNN_REQUIRE(base_a && base_b && base_c && table && n > 0 && n <= 65535 && max_tiles > 0,
+                "snn_small_gemm_batched: bad arguments");
+    hipLaunchKernelGGL(k_small_gemm_batched, dim3((unsigned)max_tiles, (unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+                       base_a, base_b, base_c, base_ct, table);
+    SNN_CHECK_LAUNCH("snn_small_gemm_batched");
     return 0;
 }
 

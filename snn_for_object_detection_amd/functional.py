@@ -778,11 +778,21 @@ class _ComposedConv1x1(Function):
         w2m = w2.detach().reshape(C2, C1)
         if not (w1m.is_contiguous() and w2m.is_contiguous()):
             w1m, w2m = w1m.contiguous(), w2m.contiguous()
-        wc = torch.empty((C2, Cin), device=x.device, dtype=_F32)   # w2 w1: [C2, Cin] = OHWI of a 1x1 kernel
-        # ... and (w2 w1)^T, the operand of the data gradient, out of the same launch (same fmaf chains: the bits a
-        # separate w1^T w2^T product would give)
-        wct = torch.empty((Cin, C2), device=x.device, dtype=_F32) if ctx.needs_input_grad[0] else None
-        _small_gemm(w2m, False, w1m, False, wc, 0, ct=wct)
+        # FlatTrainer composes every registered pair once per optimiser step in ONE launch (snn_small_gemm_batched); the
+        # pair registers itself here on first use (w2._snn_compose_with) and is served from the next refresh on, while the
+        # version counters of both weights still match.  Same fmaf chains, same bits as the per-call product.
+        cached = getattr(w2, "_snn_composed", None)
+        if (cached is not None and cached[0] is w1 and cached[1] == (w1._version, w2._version)
+                and tuple(cached[2].shape) == (C2, Cin)):
+            wc, wct = cached[2], cached[3]
+        else:
+            if getattr(w1, "_snn_wt", None) is not None and getattr(w2, "_snn_wt", None) is not None:
+                w2._snn_compose_with = w1   # both live in a FlatTrainer's flat buffer
+            wc = torch.empty((C2, Cin), device=x.device, dtype=_F32)   # w2 w1: [C2, Cin] = OHWI of a 1x1 kernel
+            # ... and (w2 w1)^T, the operand of the data gradient, out of the same launch (same fmaf chains: the bits a
+            # separate w1^T w2^T product would give)
+            wct = torch.empty((Cin, C2), device=x.device, dtype=_F32) if ctx.needs_input_grad[0] else None
+            _small_gemm(w2m, False, w1m, False, wc, 0, ct=wct)
         y = _out_tensor(dest, T, B, C2, H, W, x)
         _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), None, y.data_ptr(), cl_stride(y), T * B,
                   H, W, Cin, H, W, C2, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())

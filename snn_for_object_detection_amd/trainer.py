@@ -80,14 +80,17 @@ class FlatTrainer:
         frag_table = []
         table = []
         off = 0
+        self._offset_of = {}   # id(parameter) -> float offset in the flat buffers
         for p in self.params:
             if p.dtype != torch.float32:
                 raise RuntimeError("FlatTrainer: float32 parameters only")
             # an earlier trainer's cached images must not outlive it on the parameter (they would pass the version check)
-            for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_wfrag", "_snn_wtfrag", "_snn_grad_slot"):
+            for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_wfrag", "_snn_wtfrag", "_snn_grad_slot", "_snn_composed",
+                         "_snn_compose_with"):
                 if hasattr(p, name):
                     delattr(p, name)
             p._snn_wt_version = -1
+            self._offset_of[id(p)] = off
             view = _storage_view(self.flat_param, off, p.data)
             view.copy_(p.data)
             p.data = view
@@ -213,6 +216,37 @@ class FlatTrainer:
                       bwd_t.data_ptr(), bwd_t.shape[0], max_threads, 1, _hip.PREC_BF16X3, st)
         for p in self._conv_params:
             p._snn_wt_version = p._version
+        self._refresh_composed(st)
+
+    def _refresh_composed(self, st: int) -> None:
+        """w2 w1 (and its transpose) of every composed 1x1 pair that registered itself during a forward pass
+        (``functional._ComposedConv1x1``: ``w2._snn_compose_with = w1``), all pairs in ONE launch."""
+        pairs = [(p._snn_compose_with, p) for p in self._conv_params if getattr(p, "_snn_compose_with", None) is not None]
+        pairs = [(w1, w2) for w1, w2 in pairs if id(w1) in self._offset_of and tuple(w1.shape[2:]) == (1, 1)
+                 and tuple(w2.shape[2:]) == (1, 1) and w2.shape[1] == w1.shape[0]]
+        if not pairs:
+            return
+        key = tuple((id(w1), id(w2)) for w1, w2 in pairs)
+        if getattr(self, "_composed_key", None) != key:
+            rows, off = [], 0
+            for w1, w2 in pairs:
+                c2, c1, cin = w2.shape[0], w1.shape[0], w1.shape[1]
+                rows.append([self._offset_of[id(w2)], self._offset_of[id(w1)], off, off, c2, cin, c1])   # A = w2, B = w1
+                off += (c2 * cin + 3) // 4 * 4
+            dev = self.flat_param.device
+            self._composed_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+            self._composed_c = torch.empty(off, device=dev, dtype=torch.float32)
+            self._composed_ct = torch.empty(off, device=dev, dtype=torch.float32)
+            self._composed_tiles = max(((r[4] + 31) // 32) * ((r[5] + 31) // 32) for r in rows)
+            self._composed_rows = rows
+            self._composed_key = key
+        _hip.call("snn_small_gemm_batched", self.flat_param.data_ptr(), self.flat_param.data_ptr(),
+                  self._composed_c.data_ptr(), self._composed_ct.data_ptr(), self._composed_table.data_ptr(), len(pairs),
+                  self._composed_tiles, st)
+        for (w1, w2), r in zip(pairs, self._composed_rows):
+            c2, cin = r[4], r[5]
+            w2._snn_composed = (w1, (w1._version, w2._version), self._composed_c[r[2]:r[2] + c2 * cin].view(c2, cin),
+                                self._composed_ct[r[2]:r[2] + c2 * cin].view(cin, c2))
 
     # ------------------------------------------------------------------
     def zero_grad(self) -> None:

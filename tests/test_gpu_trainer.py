@@ -378,3 +378,64 @@ def test_event_frame_layer_forms_dy_inside_its_weight_gradient(S):
     assert res[True][1].count("snn_conv2d_wgrad_bn") == 1 and res[False][1].count("snn_conv2d_wgrad_bn") == 0
     assert res[True][1].count("snn_bn_bwd_apply") == res[False][1].count("snn_bn_bwd_apply") - 1
     assert res[True][0].abs().max() > 0 and torch.equal(res[True][0], res[False][0])
+
+
+def test_composed_1x1_weights_come_from_one_batched_launch_per_step(S):
+    """The C2f entry pairs (models/tiny_yolo.py:76-82) register themselves during the first forward pass; from the next
+    optimiser step on FlatTrainer composes w2 w1 (and its transpose) for ALL of them in one launch
+    (snn_small_gemm_batched) and the forward pass issues no composition GEMM any more - with the same bits as the per-call
+    product, and with a stale cache (weights changed behind the trainer's back) never used."""
+    from snn_for_object_detection_amd import _hip
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    T, B, H, W = 3, 2, 32, 48
+    X, labels = synthetic_events(T, B, H, W, p=0.1).cuda(), synthetic_labels(B).cuda()
+    torch.manual_seed(4)
+    model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    tr = FlatTrainer(model, lr=1e-3)
+
+    class Count:
+        def __init__(self):
+            self.names = []
+
+        def before(self, name, args):
+            self.names.append(name)
+
+        def after(self, token):
+            pass
+
+    def run():
+        tr.zero_grad()
+        loss = model.training_step((X, labels))
+        loss.backward()
+        S.functional.wgrad_stream_sync()
+        return loss.detach().clone(), tr.flat_grad.clone()
+
+    run()                                   # registers the pairs
+    tr.step()                               # update + refresh: composes them in one launch
+    pairs = [p for p in model.parameters() if getattr(p, "_snn_composed", None) is not None]
+    assert len(pairs) >= 5
+    _hip.PROFILER = cnt = Count()
+    try:
+        loss_cached, grad_cached = run()
+    finally:
+        _hip.PROFILER = None
+    n_gemm_cached = cnt.names.count("snn_small_gemm")
+    for p in pairs:
+        del p._snn_composed                 # the per-call composition again
+    _hip.PROFILER = cnt2 = Count()
+    try:
+        loss_call, grad_call = run()
+    finally:
+        _hip.PROFILER = None
+    assert cnt2.names.count("snn_small_gemm") == n_gemm_cached + len(pairs)     # one forward GEMM per pair came back
+    assert torch.equal(loss_cached, loss_call) and torch.equal(grad_cached, grad_call)
+    # a weight changed behind the trainer (version counter moved): the cached product is not used
+    tr.step()
+    with torch.no_grad():
+        pairs[0].mul_(1.5)
+    _hip.PROFILER = cnt3 = Count()
+    try:
+        run()
+    finally:
+        _hip.PROFILER = None
+    assert cnt3.names.count("snn_small_gemm") == n_gemm_cached + 1

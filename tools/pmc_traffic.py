@@ -19,7 +19,18 @@ import re
 import sys
 
 
+BF16S = False   # argv[5] == "bf16s": the passes ran bench.py --storage bf16; labels get profiler.py's ", bf16s" suffix
+
+
 def family(name: str) -> str:
+    fam = _family(name)
+    if BF16S and (fam.startswith(("k_conv_gather", "k_conv_wgrad", "k_conv_s2dgrad3", "k_conv_first", "k_affine_neuron",
+                                  "k_bn_stats", "k_bn_bwd_apply"))):
+        return fam + ", bf16s"
+    return fam
+
+
+def _family(name: str) -> str:
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     m = re.match(r"([A-Za-z0-9_:]+)", name)
     base = m.group(1) if m else name
@@ -28,11 +39,16 @@ def family(name: str) -> str:
         return f"k_conv_gather<{', '.join(a.strip() for a in t.group(1).split(',')[:5])}>" if t else base
     if base == "k_conv_halo3":  # <CO, F16, ABL, BNAP>: forward (fp16 pieces) or data gradient, as profiler.py labels them
         t = re.search(r"k_conv_halo3<(\d+), (true|false)", name)
+        if t and BF16S:
+            return f"k_conv_halo3<{t.group(1)}, bf16s>"   # one instance serves forward and data gradient
         return f"k_conv_halo3<{t.group(1)}, {'fwd' if t.group(2) == 'true' else 'dgrad'}>" if t else base
     if base == "k_conv_s2dgrad3":
         return "k_conv_s2dgrad3<dgrad>"
     if base == "k_conv_first":  # <CIN, KS, WGRAD>: the weight-gradient instance belongs to snn_conv2d_wgrad
         return "k_conv_wgrad" if re.search(r"k_conv_first<[^>]*true>", name) else "k_conv_first<2, 3, false>"
+    if base in ("k_affine_neuron_fwd", "k_affine_neuron_bwd"):   # <NEURON, ...>: profiler.py labels the neuron
+        t = re.search(base + r"<(\d+)", name)
+        return f"{base}<{t.group(1)}>" if t else base
     if base.startswith("k_conv_wgrad") or base == "k_wgrad_reduce":
         return "k_conv_wgrad"  # one snn_conv2d_wgrad call = one tile kernel (any variant) + its ordered reduce
     return base
@@ -51,6 +67,8 @@ def load(path, counter):
 
 
 def main():
+    global BF16S
+    BF16S = len(sys.argv) > 5 and sys.argv[5] == "bf16s"
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):

@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_round.sh <tag> [config]     -> gpurun_out/<tag>/
+# usage (on the GPU box): bash tools/profile_round.sh <tag> [config] [bf16]     -> gpurun_out/<tag>/
+#   third argument "bf16": the same passes on the bf16-STORAGE throughput mode (bench.py --storage bf16)
 #   bench.json + kernel_table.txt : python bench.py --kernel-table (HIP-event kernel table, roofline, CPU baseline)
 #   stats1/s_kernel_stats.csv     : rocprofv3 --kernel-trace --stats, weight-gradient side stream OFF (every kernel alone
 #                                   on the GPU: the per-kernel averages behind roofline.frac)
@@ -11,7 +12,10 @@ cfg=${2:-gen1}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
+mode=${3:-fp32}
+sfx=""
 B="--config $cfg --no-cpu-baseline"
+if [ "$mode" = "bf16" ]; then B="$B --storage bf16"; sfx="_bf16s"; fi
 export SNN_NO_WGRAD_STREAM=1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o s -- \
     python3 bench.py $B --steps 5 --warmup 2 --no-roofline > $out/stats1_bench.json 2> $out/stats1.err || exit 1
@@ -24,10 +28,10 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
     python3 bench.py $P > /dev/null 2> $out/f.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -o w -- \
     python3 bench.py $P > /dev/null 2> $out/w.err || exit 1
-python tools/pmc_traffic.py $(find $out/pmc_f -name 'f_counter_collection.csv') $(find $out/pmc_w -name 'w_counter_collection.csv') $out/traffic.json 3 > $out/traffic.txt
+python tools/pmc_traffic.py $(find $out/pmc_f -name 'f_counter_collection.csv') $(find $out/pmc_w -name 'w_counter_collection.csv') $out/traffic.json 3 ${sfx#_} > $out/traffic.txt
 # the bench line of this round quotes THESE passes: put the file where bench.py looks for it (tools/collect_profiles.sh
 # copies the same file to the same place in the repository afterwards)
-cp $out/traffic.json profiles/r03_pmc_traffic_$cfg.json
+cp $out/traffic.json profiles/r03_pmc_traffic_$cfg$sfx.json
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d $out/pmc_a -o a -- python3 bench.py $P > /dev/null 2> $out/a.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
@@ -37,7 +41,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACC
 python tools/pmc_mfma.py $out/mfma.json $(find $out/pmc_a -name 'a_counter_collection.csv') \
     $(find $out/pmc_b -name 'b_counter_collection.csv') $(find $out/pmc_c -name 'c_counter_collection.csv') > $out/mfma.txt
 unset SNN_NO_WGRAD_STREAM
-python bench.py --config $cfg --kernel-table > $out/bench.json 2> $out/kernel_table.txt || exit 1
+python bench.py ${B/--no-cpu-baseline/} --kernel-table > $out/bench.json 2> $out/kernel_table.txt || exit 1
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
 ls -R $out | head -60
