@@ -58,6 +58,9 @@ constexpr int BK = 32;   // k elements per LDS stage
 constexpr int LDK = BK + 4;
 // 3 waves / SIMD (<= 168 VGPRs): measured +5..+25 % over 2 waves / SIMD with a second LDS stage
 #define SNN_CONV_MIN_WAVES 3
+#ifndef SNN_GATHER_SB_WAVES
+#define SNN_GATHER_SB_WAVES 3   // waves per SIMD the bf16-storage instances of the pipelined kernel are compiled for
+#endif
 
 struct ConvGeom {
     int64_t Mtot;      // GEMM rows: img * OH * OW (FWD) or img * OHc * OWc (DGRAD, one stride-phase class)
@@ -171,7 +174,7 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // (strides in elements).  The gathered rows arrive as 8-byte loads and go to LDS as they are - no conversion; the
 // epilogue rounds the fp32 accumulators to bf16 on their way out.  Weights stay fp32 and are rounded in the loader.
 template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false, bool SB = false>
-__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : 2) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
+__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? SNN_GATHER_SB_WAVES : 2)) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add,
                                                           const float* __restrict__ addend2, int64_t ld_add2) {

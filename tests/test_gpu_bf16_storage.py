@@ -341,3 +341,41 @@ def test_bf16_storage_training_step_tolerance_and_dtypes(H_):
     assert abs(loss32.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
     with pytest.raises(ValueError):
         HF.set_activation_storage("fp16")
+
+
+def test_bf16_storage_with_the_trainer_and_the_other_entry_points(H_):
+    """The mode through the rest of the API: FlatTrainer steps (its per-step forward weight image switches to bf16 pieces),
+    streaming ``predict`` with carried fp32 state, the literal time-outer loop and the layer-major pass in eval mode (the two
+    orders agree to the mode's resolution: they round the same values at the same places, only sums differ in order)."""
+    import snn_for_object_detection_amd as S
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    HF = S.functional
+    _hip = H_
+    T, B, H, W = 4, 2, 32, 48
+    torch.manual_seed(3)
+    model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    X, labels = synthetic_events(T, B, H, W, p=0.1).cuda(), synthetic_labels(B).cuda()
+    HF.set_activation_storage("bf16")
+    try:
+        tr = FlatTrainer(model, lr=2e-3)
+        losses = []
+        for _ in range(6):
+            tr.zero_grad()
+            loss = model.training_step((X, labels))
+            loss.backward()
+            tr.step()
+            losses.append(loss.item())
+        assert all(torch.isfinite(torch.tensor(losses))) and min(losses[1:]) < losses[0]
+        assert {getattr(p, "_snn_wfrag_prec", None) for p in model.parameters()} == {_hip.PREC_BF16X3, None}
+        model.eval()
+        with torch.no_grad():
+            state = None
+            for t in range(T):
+                det, state = model.predict(X[t, 0], state)
+            assert det.dtype == torch.float32 and det.dim() == 2 and det.shape[1] == 6
+            outer = model(X, time_outer=True)
+            major = model(X)
+        assert all(t.dtype == torch.float32 for t in outer) and all(t.dtype == torch.float32 for t in major)
+        assert float((outer[1] - major[1]).abs().max()) < 5e-3 and float((outer[2] - major[2]).abs().max()) < 5e-3
+    finally:
+        HF.set_activation_storage("fp32")
