@@ -351,6 +351,13 @@ int snn_add_channels(const float* src, int64_t lds, float* dst, int64_t ldd, int
 /* dst = a + b over M pixels x C channels, each operand with its own pixel stride */
 int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst, int64_t ldd,
             int64_t M, int C, void* stream);
+/* the same merges on bf16 tensors (bf16-storage mode, see SNN_PREC_BF16S; pointers typed float*, strides in elements; the sum
+ * is formed in fp32 and rounded once), and the conversion at the boundary of the bf16 domain (dense, n elements;
+ * to_bf16 != 0: fp32 -> bf16 round to nearest even, else bf16 -> fp32) */
+int snn_copy_channels_bf16(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
+int snn_add_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst, int64_t ldd, int64_t M, int C,
+                 void* stream);
+int snn_convert_bf16(const void* src, void* dst, int64_t n, int to_bf16, void* stream);
 int snn_act_fwd(int act, const float* x, float* y, int64_t n, void* stream);
 int snn_act_bwd(int act, const float* x, const float* y, const float* gy, float* gx, int64_t n, void* stream);
 

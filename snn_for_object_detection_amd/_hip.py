@@ -90,6 +90,9 @@ SIGNATURES = {
     "snn_det_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "snn_small_gemm": (c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "snn_small_gemm_batched": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "snn_copy_channels_bf16": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
+    "snn_add_bf16": (c_int, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
+    "snn_convert_bf16": (c_int, [_P, _P, _L, _I, _P]),
     "snn_act_fwd": (c_int, [_I, _P, _P, _L, _P]),
     "snn_act_bwd": (c_int, [_I, _P, _P, _P, _P, _L, _P]),
     "snn_lstm_cell_fwd": (c_int, [_P, _P, _P, _P, _L, _I, _P]),

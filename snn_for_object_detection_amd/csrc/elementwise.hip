@@ -134,6 +134,38 @@ __global__ void k_add(const float* __restrict__ a, int64_t lda, const float* __r
     }
 }
 
+// the merges of the bf16-storage mode (SnnStore<true>, snn_common.h): bf16 tensors, the sum formed in fp32 and rounded once.
+// MODE 0: dst = a (copy), 1: dst = a + b.  VEC 4 (8-byte accesses) or 1.
+template <int VEC, int MODE>
+__global__ void k_merge_bf16(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                             float* __restrict__ dst, int64_t ldd, int64_t M, int C) {
+    typedef SnnStore<true> St;
+    const int cv = C / VEC;
+    const int64_t total = M * cv;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t m = e / cv;
+        const int c = (int)(e % cv) * VEC;
+        if (VEC == 4) {
+            f32x4 v = St::ld4(a, m * lda + c);
+            if (MODE == 1) v += St::ld4(b, m * ldb + c);
+            St::st4(dst, m * ldd + c, v);
+        } else {
+            float v = St::ld1(a, m * lda + c);
+            if (MODE == 1) v += St::ld1(b, m * ldb + c);
+            St::st1(dst, m * ldd + c, v);
+        }
+    }
+}
+
+// fp32 <-> bf16 (round to nearest even), dense: the boundary of the bf16-storage domain (the head's last-step read-out)
+template <bool TO_BF16>
+__global__ void k_convert_bf16(const void* __restrict__ src, void* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        if (TO_BF16) SnnStore<true>::st1(dst, i, static_cast<const float*>(src)[i]);
+        else static_cast<float*>(dst)[i] = SnnStore<true>::ld1(src, i);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ activations
 __device__ __forceinline__ float act_f(int act, float x) {
     switch (act) {
@@ -491,6 +523,39 @@ extern "C" int snn_add(const float* a, int64_t lda, const float* b, int64_t ldb,
     else hipLaunchKernelGGL(k_add<1>, dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, a, lda, b, ldb,
                             dst, ldd, M, C);
     SNN_CHECK_LAUNCH("snn_add");
+    return 0;
+}
+
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+extern "C" int snn_copy_channels_bf16(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream) {
+    SNN_REQUIRE(src && dst && M > 0 && C > 0 && lds >= C && ldd >= C, "snn_copy_channels_bf16: bad arguments");
+    const bool v4 = C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && aligned8(src) && aligned8(dst);
+    if (v4) hipLaunchKernelGGL((k_merge_bf16<4, 0>), dim3(grid_for(M * (C / 4))), dim3(kThreads), 0, (hipStream_t)stream, src,
+                               lds, nullptr, 0, dst, ldd, M, C);
+    else hipLaunchKernelGGL((k_merge_bf16<1, 0>), dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, src, lds,
+                            nullptr, 0, dst, ldd, M, C);
+    SNN_CHECK_LAUNCH("snn_copy_channels_bf16");
+    return 0;
+}
+
+extern "C" int snn_add_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, float* dst, int64_t ldd, int64_t M,
+                            int C, void* stream) {
+    SNN_REQUIRE(a && b && dst && M > 0 && C > 0 && lda >= C && ldb >= C && ldd >= C, "snn_add_bf16: bad arguments");
+    const bool v4 = C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldd % 4 == 0 && aligned8(a) && aligned8(b) && aligned8(dst);
+    if (v4) hipLaunchKernelGGL((k_merge_bf16<4, 1>), dim3(grid_for(M * (C / 4))), dim3(kThreads), 0, (hipStream_t)stream, a,
+                               lda, b, ldb, dst, ldd, M, C);
+    else hipLaunchKernelGGL((k_merge_bf16<1, 1>), dim3(grid_for(M * C)), dim3(kThreads), 0, (hipStream_t)stream, a, lda, b,
+                            ldb, dst, ldd, M, C);
+    SNN_CHECK_LAUNCH("snn_add_bf16");
+    return 0;
+}
+
+extern "C" int snn_convert_bf16(const void* src, void* dst, int64_t n, int to_bf16, void* stream) {
+    SNN_REQUIRE(src && dst && n > 0, "snn_convert_bf16: bad arguments");
+    if (to_bf16) hipLaunchKernelGGL(k_convert_bf16<true>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, src, dst, n);
+    else hipLaunchKernelGGL(k_convert_bf16<false>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, src, dst, n);
+    SNN_CHECK_LAUNCH("snn_convert_bf16");
     return 0;
 }
 

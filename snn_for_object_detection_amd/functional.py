@@ -323,10 +323,8 @@ def _raw_dense_cl(x: torch.Tensor) -> torch.Tensor:
     for d in lead:
         n *= d
     out = _new_cl(lead, C, H, W, x)
-    if x.dtype == _BF16:
-        out.copy_(x)
-        return out
-    _hip.call("snn_copy_channels", x.data_ptr(), cl_stride(x), out.data_ptr(), C, n * H * W, C, _stream())
+    _hip.call("snn_copy_channels_bf16" if x.dtype == _BF16 else "snn_copy_channels", x.data_ptr(), cl_stride(x),
+              out.data_ptr(), C, n * H * W, C, _stream())
     return out
 
 
@@ -852,7 +850,7 @@ class _ComposedConv1x1(Function):
 def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: Optional[Dest] = None,
                      forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
     if x.dtype == _BF16 and (w1.shape[1] % 32 or w2.shape[0] % 32):   # (see conv2d)
-        y = composed_conv1x1(x.float(), w1, w2, None, forward_precision, backward_precision).to(_BF16)
+        y = to_bfloat16(composed_conv1x1(to_float32(x), w1, w2, None, forward_precision, backward_precision))
         return place(y, dest) if dest is not None else y
     seq, single = as_sequence(x)
     y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq),
@@ -880,7 +878,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
     if x.dtype == _BF16 and (weight.shape[1] % 32 or weight.shape[0] % 32):
         # bf16 storage: the kernels want whole 32-channel k-steps (forward: Cin, data gradient: Cout); other layers - a
         # prediction head applied to every timestep - take the fp32 kernels between two conversions
-        y = conv2d(x.float(), weight, stride, padding, None, forward_precision, backward_precision, False).to(_BF16)
+        y = to_bfloat16(conv2d(to_float32(x), weight, stride, padding, None, forward_precision, backward_precision, False))
         return place(y, dest) if dest is not None else y
     seq, single = as_sequence(x)
     bn_out = [] if bn_stats else None
@@ -1062,7 +1060,7 @@ class _AffineNeuron(Function):
             ctx.mark_non_differentiable(vT, iT)
         # with a neuron, vT / iT stay differentiable (time-outer BPTT through the carried state)
         if sb and last_only:
-            out = out.float()   # the read-out of the last step (a few frames) leaves the bf16 domain here
+            out = _raw_convert(out, _F32)   # the read-out of the last step (a few frames) leaves the bf16 domain here
         return out, vT, iT
 
     @staticmethod
@@ -1083,7 +1081,7 @@ class _AffineNeuron(Function):
             g_out = torch.zeros((B, H, W, C) if ctx.last_only else (T, B, H, W, C), device=dev, dtype=y.dtype)
             g_out = _cl_view(g_out)
         if g_out.dtype != y.dtype:
-            g_out = g_out.to(y.dtype)   # (bf16 storage: the fp32 gradient of the last-step read-out)
+            g_out = _raw_convert(g_out, y.dtype)   # (bf16 storage: the fp32 gradient of the last-step read-out)
         g_out = _raw_to_cl(g_out)
         es = y.element_size()
         scan_flags = SCAN_FLAGS | (_hip.SCAN_LAST_STEP_ONLY if ctx.last_only else 0) | (_hip.SCAN_BF16_STORAGE if sb else 0)
@@ -1227,9 +1225,9 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
     if y.dtype == _BF16 and (neuron not in (_hip.NEURON_NONE, _hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH)
                              or y.shape[-3] % 4):
         # no bf16-storage form of this scan (SLI / Synapse, channel counts that are not a multiple of 4): see _through_fp32
-        out, new_state = affine_neuron(y.float(), neuron, state, bn, params, None, None if addend is None else addend.float(),
-                                       last_only)
-        out = out if (last_only and y.dim() == 5) else out.to(_BF16)
+        out, new_state = affine_neuron(to_float32(y), neuron, state, bn, params, None,
+                                       None if addend is None else to_float32(addend), last_only)
+        out = out if (last_only and y.dim() == 5) else to_bfloat16(out)
         return (place(out, dest) if dest is not None else out), new_state
     bn_hint = getattr(y, "_snn_bn_partial", None)
     defer_apply = bool(getattr(y, "_snn_defer_apply", False))
@@ -1282,23 +1280,18 @@ def _copy_cl(src: torch.Tensor, dst: torch.Tensor) -> None:
     """dst = src, both (possibly channel-sliced) channels-last ``[T,B,C,H,W]``."""
     if src.dtype != dst.dtype:
         raise RuntimeError("merge: operands are stored in different types (fp32 / bf16 storage mixed)")
-    if src.dtype == _BF16:   # bf16 storage: copying merges are off the hot path (the Dense merge is zero-copy) - torch's copy
-        dst.copy_(src)
-        return
     T, B, C, H, W = _dims5(src)
-    _hip.call("snn_copy_channels", src.data_ptr(), cl_stride(src), dst.data_ptr(), cl_stride(dst), T * B * H * W, C, _stream())
+    _hip.call("snn_copy_channels_bf16" if src.dtype == _BF16 else "snn_copy_channels", src.data_ptr(), cl_stride(src),
+              dst.data_ptr(), cl_stride(dst), T * B * H * W, C, _stream())
 
 
 def _add_cl(a: torch.Tensor, b: torch.Tensor, dst: torch.Tensor) -> None:
     """dst = a + b over channels-last ``[T,B,C,H,W]`` operands with their own pixel strides (dst may be a)."""
     if not (a.dtype == b.dtype == dst.dtype):
         raise RuntimeError("merge: operands are stored in different types (fp32 / bf16 storage mixed)")
-    if a.dtype == _BF16:     # bf16 storage: one rounding of the fp32 sum (torch's elementwise add)
-        torch.add(a, b, out=dst)
-        return
-    T, B, C, H, W = _dims5(a)
-    _hip.call("snn_add", a.data_ptr(), cl_stride(a), b.data_ptr(), cl_stride(b), dst.data_ptr(), cl_stride(dst),
-              T * B * H * W, C, _stream())
+    T, B, C, H, W = _dims5(a)   # (bf16 storage: the sum is formed in fp32 and rounded once)
+    _hip.call("snn_add_bf16" if a.dtype == _BF16 else "snn_add", a.data_ptr(), cl_stride(a), b.data_ptr(), cl_stride(b),
+              dst.data_ptr(), cl_stride(dst), T * B * H * W, C, _stream())
 
 
 class _Concat(Function):
@@ -1546,13 +1539,51 @@ class _Act(Function):
         return gx, None
 
 
+def _raw_convert(x: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 <-> bf16 copy of a tensor in the same memory order (snn_convert_bf16; round to nearest even).  Dense
+    channels-last or contiguous tensors are converted in place order; anything else is made dense channels-last first."""
+    if x.dtype == dtype:
+        return x
+    _require_device(x, "storage conversion", bf16_ok=True)
+    if x.dim() >= 3 and not x.is_contiguous():
+        x = _raw_dense_cl(x)
+        out = _new_cl(x.shape[:-3], *x.shape[-3:], x, dtype)
+    else:
+        x = x.contiguous()
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    if x.numel():
+        _hip.call("snn_convert_bf16", x.data_ptr(), out.data_ptr(), x.numel(), 1 if dtype == _BF16 else 0, _stream())
+    return out
+
+
+class _Convert(Function):
+    """Leaves / enters the bf16-storage domain: the gradient crosses the boundary the other way."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return _raw_convert(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _raw_convert(g, ctx.src_dtype), None
+
+
+def to_float32(x: torch.Tensor) -> torch.Tensor:
+    return x if x.dtype == _F32 else _Convert.apply(x, _F32)
+
+
+def to_bfloat16(x: torch.Tensor) -> torch.Tensor:
+    return x if x.dtype == _BF16 else _Convert.apply(x, _BF16)
+
+
 def _through_fp32(op, x: torch.Tensor, *args):
     """Operators without a bf16-storage kernel (activations, pooling, up-sampling, ConvLSTM, SLI / Synapse: none of them is
     on the TinyYolo path) still work in that mode: the tensor is widened to fp32 for the operator and its result is
     narrowed again (two conversion passes - correct, not fast)."""
     if x.dtype != _BF16:
         return op(x, *args)
-    return op(x.float(), *args).to(_BF16)
+    return to_bfloat16(op(to_float32(x), *args))
 
 
 def activation(x: torch.Tensor, act: int) -> torch.Tensor:
@@ -1660,8 +1691,8 @@ class _LstmCell(Function):
 
 def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]):
     if gates.dtype == _BF16:   # (see _through_fp32) the cell state c stays fp32 across the steps
-        h, c = _LstmCell.apply(gates.float(), None if c_prev is None else c_prev.float())
-        return h.to(_BF16), c
+        h, c = _LstmCell.apply(to_float32(gates), None if c_prev is None else to_float32(c_prev))
+        return to_bfloat16(h), c
     return _LstmCell.apply(gates, c_prev)
 
 

@@ -446,13 +446,13 @@ class HeadGen(ModelGen):
         if Y.dim() == 5 and keep_last:
             Y = Y[-1]
         if keep_last and Y.dtype == torch.bfloat16:
-            Y = Y.float()   # bf16-storage mode: the last-step read-out (a few frames) and the prediction nets run in fp32
+            Y = HF.to_float32(Y)   # bf16-storage mode: the last-step read-out (a few frames) and the prediction nets run in fp32
         box, state[1] = self.box_net(Y, state[1])
         cls, state[2] = self.cls_net(Y, state[2])
         if box.dim() == 5:
             box, cls = box[-1], cls[-1]
         if box.dtype == torch.bfloat16:
-            box, cls = box.float(), cls.float()
+            box, cls = HF.to_float32(box), HF.to_float32(cls)
         return box, cls, state
 
 

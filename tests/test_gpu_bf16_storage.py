@@ -379,3 +379,38 @@ def test_bf16_storage_with_the_trainer_and_the_other_entry_points(H_):
         assert float((outer[1] - major[1]).abs().max()) < 5e-3 and float((outer[2] - major[2]).abs().max()) < 5e-3
     finally:
         HF.set_activation_storage("fp32")
+
+
+def test_bf16_storage_merges_and_the_domain_boundary(H_):
+    """Copy / add of (channel-sliced) bf16 tensors and the fp32 <-> bf16 conversion at the boundary of the bf16 domain:
+    the sum is formed in fp32 and rounded once (= torch's bf16 add), conversions round to nearest even (= torch's cast)."""
+    _hip = H_
+    from snn_for_object_detection_amd import functional as HF
+    torch.manual_seed(23)
+    st = _st()
+    M, C = 777, 40
+    for C, lda, ldb, ldd, oa, ob, od in ((40, 64, 48, 56, 8, 4, 12), (6, 7, 9, 6, 1, 2, 0)):   # 8-byte accesses / scalar path
+        abuf = torch.randn(M, lda, device="cuda").to(BF)
+        bbuf = torch.randn(M, ldb, device="cuda").to(BF)
+        dbuf = torch.full((M, ldd), 7.0, device="cuda", dtype=BF)
+        a, b, d = abuf[:, oa:oa + C], bbuf[:, ob:ob + C], dbuf[:, od:od + C]
+        _hip.call("snn_add_bf16", a.data_ptr(), lda, b.data_ptr(), ldb, d.data_ptr(), ldd, M, C, st)
+        assert torch.equal(d, a + b)
+        assert bool((dbuf[:, :od] == 7.0).all()) and bool((dbuf[:, od + C:] == 7.0).all())
+        _hip.call("snn_copy_channels_bf16", b.data_ptr(), ldb, d.data_ptr(), ldd, M, C, st)
+        assert torch.equal(d, b)
+    x = torch.randn(5, 33, 17, device="cuda") * 3
+    x[0, 0, 0], x[0, 0, 1] = float("inf"), 1e-40
+    y = torch.empty(x.shape, device="cuda", dtype=BF)
+    _hip.call("snn_convert_bf16", x.data_ptr(), y.data_ptr(), x.numel(), 1, st)
+    assert torch.equal(y, x.to(BF))
+    z = torch.empty_like(x)
+    _hip.call("snn_convert_bf16", y.data_ptr(), z.data_ptr(), x.numel(), 0, st)
+    assert torch.equal(z, y.float())
+    # autograd form: the gradient crosses the boundary the other way
+    t = (torch.randn(2, 3, 8, 5, 6, device="cuda")).to(BF).requires_grad_()
+    f = HF.to_float32(t)
+    assert f.dtype == torch.float32 and torch.equal(f, t.detach().float())
+    g = torch.randn_like(f)
+    f.backward(g)
+    assert t.grad.dtype == BF and torch.equal(t.grad, g.to(BF))
