@@ -59,7 +59,9 @@ constexpr int LDK = BK + 4;
 // 3 waves / SIMD (<= 168 VGPRs): measured +5..+25 % over 2 waves / SIMD with a second LDS stage
 #define SNN_CONV_MIN_WAVES 3
 #ifndef SNN_GATHER_SB_WAVES
-#define SNN_GATHER_SB_WAVES 3   // waves per SIMD the bf16-storage instances of the pipelined kernel are compiled for
+#define SNN_GATHER_SB_WAVES 3   // waves per SIMD the bf16-storage FORWARD instances of the pipelined kernel are compiled for
+                                // (same-call A/B: 2 -> 3 waves 88 -> 79 us; 4 spills 13 registers, 80 us); the data-gradient
+                                // instances (no statistics) fit 4 waves: 88 -> 81 us
 #endif
 
 struct ConvGeom {
@@ -174,7 +176,7 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // (strides in elements).  The gathered rows arrive as 8-byte loads and go to LDS as they are - no conversion; the
 // epilogue rounds the fp32 accumulators to bf16 on their way out.  Weights stay fp32 and are rounded in the loader.
 template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false, bool SB = false>
-__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? SNN_GATHER_SB_WAVES : 2)) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
+__global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (DGRAD ? 4 : SNN_GATHER_SB_WAVES) : 2)) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add,
                                                           const float* __restrict__ addend2, int64_t ld_add2) {
