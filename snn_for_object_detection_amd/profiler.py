@@ -73,7 +73,7 @@ def work_of(name: str, a):
         flops = 2.0 * n * h * w * cout * 9 * cin
         byts = es * (n * h * w * cin + n * h * w * cout) + 4.0 * cout * 9 * cin
         kind = "fwd" if prec == 4 else ("dgrad" if prec == 1 else "bf16s")   # (bf16 storage: one instance serves both)
-        return f"k_conv_halo3<{128 if cout % 128 == 0 else 64}, {kind}>", flops, byts
+        return f"k_conv_halo3<{128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)}, {kind}>", flops, byts
     if name == "snn_conv3x3_halo_bn":   # the same data gradient with the BatchNorm-backward affine applied while staging
         n, h, w, cin, cout = a[8], a[9], a[10], a[11], a[12]
         flops = 2.0 * n * h * w * cout * 9 * cin
