@@ -170,3 +170,32 @@ def test_unbounded_activation_status_reaches_every_convolution_it_feeds():
     assert getattr(gen, "forward_precision", None) is None                   # an explicit setting is respected
     m = S.TinyYolo(num_classes=2, time_window=0)
     assert all(c.forward_precision is None for c in m.modules() if isinstance(c, torch.nn.Conv2d))
+
+
+def test_profiler_byte_model_of_both_storage_modes():
+    """bench.py's per-launch work model (profiler.work_of): activation tensors count 4 bytes per element, 2 in the bf16-storage
+    mode (weights and weight gradients stay fp32; the event frames stay fp32), last-step-only scans write one step, and the
+    labels of the bf16 instances carry the suffix bench.py keys the bf16 MFMA peak on."""
+    from snn_for_object_detection_amd.profiler import work_of
+    N, H, W, Cin, Cout = 160, 30, 38, 128, 128
+    px = N * H * W
+    # snn_conv3x3_halo(x, ldx, img, y, ldy, N, H, W, Cin, Cout, add, ld, add2, ld2, partial, fps, layout, precision, stream)
+    base = [1, Cin, 2, 3, Cout, N, H, W, Cin, Cout, None, 0, None, 0, None, 0, None]
+    l32, f32, b32 = work_of("snn_conv3x3_halo", base + [4, 0])
+    l16, f16, b16 = work_of("snn_conv3x3_halo", base + [6, 0])
+    assert l32 == "k_conv_halo3<128, fwd>" and l16 == "k_conv_halo3<128, bf16s>" and f32 == f16 == 2.0 * px * Cout * 9 * Cin
+    assert b32 == 4.0 * (2 * px * Cin) + 4.0 * Cout * 9 * Cin and b16 == 2.0 * (2 * px * Cin) + 4.0 * Cout * 9 * Cin
+    assert work_of("snn_conv3x3_halo", [1, 32, 2, 3, 32, N, H, W, 32, 32] + base[10:] + [1, 0])[0] == "k_conv_halo3<32, dgrad>"
+    # snn_affine_neuron_fwd(neuron, y, ldy, alpha, beta, v0, i0, out, ldo, addend, ld, vT, iT, vdec, T, M, C, params, flags, stream)
+    T, M, C = 32, 5700, 128
+    scan = [1, 1, C, 2, 3, None, None, 4, C, None, 0, 5, 6, 7, T, M, C, None]
+    assert work_of("snn_affine_neuron_fwd", scan + [0, 0])[2] == 4.0 * T * M * C * 3          # y, out, vdec
+    assert work_of("snn_affine_neuron_fwd", scan + [4, 0])[2] == 2.0 * T * M * C * 3
+    assert work_of("snn_affine_neuron_fwd", scan + [4, 0])[0].endswith(", bf16s")
+    assert work_of("snn_affine_neuron_fwd", scan + [2, 0])[2] == 4.0 * T * M * C * (2 + 1.0 / T)   # one step of out
+    # the event-frame layer in bf16 storage: fp32 frames in, bf16 out
+    # snn_conv2d_fwd(x, ldx, w, w_split, y, ldy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, add, ld, partial, fps, layout, prec, st)
+    first = [1, 2, 2, None, 3, 64, N, 240, 304, 2, 240, 304, 64, 3, 3, 1, 1, None, 0, None, 0, None]
+    lab, _, byts = work_of("snn_conv2d_fwd", first + [6, 0])
+    assert lab.startswith("k_conv_first") and byts == 4.0 * N * 240 * 304 * 2 + 2.0 * N * 240 * 304 * 64 + 4.0 * 64 * 9 * 2
+    assert work_of("snn_bn_bwd_apply_bf16", [0] * 8 + [T, M, C])[2] == 6.0 * T * M * C
