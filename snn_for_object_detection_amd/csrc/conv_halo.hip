@@ -547,7 +547,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
 // their class: kh = 1 -> even rows from dy row a; kh = 0 -> odd rows from dy row a + 1; kh = 2 -> odd rows from dy row a
 // (columns alike).  Four accumulator sets of 32 cells x 64 channels per wave (128 registers), 4 waves over the cells,
 // 64 dx channels per block.  The weight image is the stride-1 data-gradient image (mirrored taps): tap t is read at 8 - t.
-template <bool SBF = false>   // SBF: dy, dx and the addends are bf16 tensors, one product (see k_conv_halo3)
+// RECT (dy rows longer than 157 cells: the strip halo would not fit): a block owns a 4 x 32 rectangle of dy cells of ONE image,
+// one row per wave; the staged halo is that rectangle plus one row below and one column to the right (5 x 33 cells).
+constexpr int SPITCH = RTW + 1, SCELLS = (RTH + 1) * SPITCH;
+template <bool SBF = false, bool RECT = false>   // SBF: dy, dx and the addends are bf16 tensors, one product (see k_conv_halo3)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __restrict__ x,   // dy
                                                               const unsigned char* __restrict__ wimg,
                                                               float* __restrict__ y,         // dx
@@ -569,10 +572,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
     const int tile = (blockIdx.x & 7) * g.tiles_per_xcd + bq / g.ntiles_n;
     if (tile >= g.tiles) return;
     const int n0c = (bq % g.ntiles_n) * CO;
-    const int c0 = tile * HBM_;                                  // one group: all N images
-    const int R0g = c0 / g.PW, x0 = c0 - R0g * g.PW;
-    const int n0 = R0g / g.PH, y0 = R0g - n0 * g.PH;
+    int c0 = 0, x0 = 0, y0 = 0, n0;
+    [[maybe_unused]] int ty = 0, tx = 0;
+    if constexpr (RECT) {
+        n0 = tile / g.tiles_img;
+        const int rem = tile - n0 * g.tiles_img;
+        ty = rem / g.tiles_x;
+        tx = rem - ty * g.tiles_x;
+    } else {
+        c0 = tile * HBM_;                                        // one group: all N images
+        const int R0g = c0 / g.PW;
+        x0 = c0 - R0g * g.PW;
+        n0 = R0g / g.PH;
+        y0 = R0g - n0 * g.PH;
+    }
     const int nb = n0;                                           // the halo reaches forward only
+    const int pitch = RECT ? SPITCH : g.PW;
 
     const int quad = tid & 7;
     const int64_t ipix = (int64_t)g.H * g.W;
@@ -585,19 +600,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int cell = p * 32 + (tid >> 3);                    // halo cell = strip cell (tile start) + cell
-        const unsigned u = (unsigned)(x0 + cell);
-        const unsigned dR = udiv_small(u, g.magic_pw);
-        const int xx = (int)(u - dR * g.PW);
-        const unsigned v = (unsigned)(y0 + (int)dR);
-        const unsigned dn = udiv_small(v, g.magic_ph);
-        const int yy = (int)(v - dn * g.PH);
-        const int n = n0 + (int)dn;
-        const bool ok = n < g.N && xx < g.W && yy < g.H;
+        int xx, yy, n;
+        bool ok;
+        if constexpr (RECT) {
+            const int rr = cell / SPITCH, cc = cell - rr * SPITCH;
+            yy = ty * RTH + rr;
+            xx = tx * RTW + cc;
+            n = n0;
+            ok = cell < SCELLS && xx < g.W && yy < g.H;
+        } else {
+            const unsigned u = (unsigned)(x0 + cell);
+            const unsigned dR = udiv_small(u, g.magic_pw);
+            xx = (int)(u - dR * g.PW);
+            const unsigned v = (unsigned)(y0 + (int)dR);
+            const unsigned dn = udiv_small(v, g.magic_ph);
+            yy = (int)(v - dn * g.PH);
+            n = n0 + (int)dn;
+            ok = n < g.N && xx < g.W && yy < g.H;
+        }
         const int64_t pix = (int64_t)(n - nb) * ipix + (int64_t)yy * g.W + xx;
         voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * ES) : 0x80000000u;
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
     }
-    const int cellbase = wave * 32 + r;
+    const int cellbase = RECT ? wave * SPITCH + r : wave * 32 + r;
     const int nchunks = g.Cin >> 5;
     const int co_tiles = g.Cout >> 5;
     const unsigned char* wsrc = wimg + (int64_t)(n0c >> 5) * 4096 + lane * 16;
@@ -688,7 +713,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
             // kh = 1: even dx rows, dy row a; kh = 0: odd rows, dy row a + 1; kh = 2: odd rows, dy row a (columns alike)
             const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
             const int dh = kh == 0 ? 1 : 0, dw = kw == 0 ? 1 : 0;
-            kstep(dh * g.PW + dw, Bimg + cur * BTILE, acc[2 * ph + pw]);
+            kstep(dh * pitch + dw, Bimg + cur * BTILE, acc[2 * ph + pw]);
             asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (more) {
@@ -717,15 +742,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
         for (int pass = 0; pass < 32 / RPP; ++pass) {
             const int row = pass * RPP + lrow;
             const int m = wave * 32 + row;
-            const unsigned u = (unsigned)(x0 + m);
-            const unsigned dR = udiv_small(u, g.magic_pw);
-            const int bb = (int)(u - dR * g.PW);
-            const unsigned v = (unsigned)(y0 + (int)dR);
-            const unsigned dn = udiv_small(v, g.magic_ph);
-            const int aa = (int)(v - dn * g.PH);
-            const int n = n0 + (int)dn;
+            int aa, bb, n;
+            bool inside;
+            if constexpr (RECT) {
+                aa = ty * RTH + wave;
+                bb = tx * RTW + row;
+                n = n0;
+                inside = true;
+            } else {
+                const unsigned u = (unsigned)(x0 + m);
+                const unsigned dR = udiv_small(u, g.magic_pw);
+                bb = (int)(u - dR * g.PW);
+                const unsigned v = (unsigned)(y0 + (int)dR);
+                const unsigned dn = udiv_small(v, g.magic_ph);
+                aa = (int)(v - dn * g.PH);
+                n = n0 + (int)dn;
+                inside = m < cells_left && n < g.N;
+            }
             const int hi = 2 * aa + ph, wi = 2 * bb + pw;
-            const bool ok = m < cells_left && bb < g.W && aa < g.H && hi < g.OH && wi < g.OW && n < g.N && nch < g.Cout;
+            const bool ok = inside && bb < g.W && aa < g.H && hi < g.OH && wi < g.OW && nch < g.Cout;
             f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * EW + c4]);
             if (!ok) continue;
             const int64_t pix = ((int64_t)n * g.OH + hi) * g.OW + wi;
@@ -820,12 +855,14 @@ static int halo_mode(int64_t N, int H, int W, int Cin, int Cout) {
 }
 static bool halo_shape_ok(int64_t N, int H, int W, int Cin, int Cout) { return halo_mode(N, H, W, Cin, Cout) != 0; }
 
+// strip tiles need the tile and the PW + 1 cells behind it inside the staged halo; wider rows take 4 x 32 rectangles
+static bool s2dgrad_rect(int Wo) { return 128 + (Wo + 1) + 2 > HCELLS; }
 static bool s2dgrad_shape_ok(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout) {
     // Cin: the layer's input channels (dx), Cout: its output channels (dy, the K dimension)
     if (N <= 0 || H <= 0 || W <= 0) return false;
     if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return false;     // 3x3, stride 2, pad 1
     if (Cout % 32 != 0 || Cout < 32 || Cin % 64 != 0) return false;
-    if (128 + (Wo + 1) + 2 > HCELLS) return false;                        // the tile and the PW + 1 cells behind it
+    if (s2dgrad_rect(Wo)) return N * snn_ceil_div(Ho, RTH) * snn_ceil_div(Wo, RTW) < 0x7fffffffLL;   // rectangles: any width
     if (N * (int64_t)(Ho + 1) * (Wo + 1) >= 0x7fffffffLL) return false;
     return true;
 }
@@ -851,7 +888,6 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
                 "snn_conv3x3_s2_dgrad: dy (16 bytes; 8 for bf16) and the weight image (16) must be aligned");
     SNN_REQUIRE(!addend || ld_addend >= Cin, "snn_conv3x3_s2_dgrad: addend pixel stride smaller than channel count");
     SNN_REQUIRE(!addend2 || ld_addend2 >= Cin, "snn_conv3x3_s2_dgrad: addend2 pixel stride smaller than channel count");
-    SNN_REQUIRE((int64_t)4 * Ho * Wo * lddy * 4 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: four dy images must span less than 2 GiB");
     HaloGeom g;
     g.ldx = lddy; g.ldy = lddx; g.ld_add = ld_addend; g.ld_add2 = ld_addend2;
     g.N = (int)N; g.H = Ho; g.W = Wo;          // the strip grid is dy's
@@ -860,10 +896,21 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
     g.OH = H; g.OW = W;
     g.PW = Wo + 1; g.PH = Ho + 1;
     g.G = (int)N;
-    const int64_t cells = N * (int64_t)g.PH * g.PW;
-    g.group_cells = (int)cells;
-    g.tiles_per_group = (int)snn_ceil_div(cells, HBM_);
-    g.tiles = g.tiles_per_group;
+    const bool rect = s2dgrad_rect(Wo);
+    g.tiles_x = (int)snn_ceil_div(Wo, RTW);
+    g.tiles_img = g.tiles_x * (int)snn_ceil_div(Ho, RTH);
+    if (rect) {
+        g.group_cells = 0;
+        g.tiles_per_group = g.tiles_img;
+        g.tiles = (int)(N * g.tiles_img);
+        SNN_REQUIRE((int64_t)Ho * Wo * lddy * 4 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: a dy image must span less than 2 GiB");
+    } else {
+        SNN_REQUIRE((int64_t)4 * Ho * Wo * lddy * 4 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: four dy images must span less than 2 GiB");
+        const int64_t cells = N * (int64_t)g.PH * g.PW;
+        g.group_cells = (int)cells;
+        g.tiles_per_group = (int)snn_ceil_div(cells, HBM_);
+        g.tiles = g.tiles_per_group;
+    }
     g.ntiles_n = Cin / 64;
     SNN_REQUIRE((int64_t)g.tiles * g.ntiles_n + 8 < 0x7fffffffLL, "snn_conv3x3_s2_dgrad: grid too large");
     g.tiles_per_xcd = (int)snn_ceil_div(g.tiles, 8);
@@ -872,14 +919,16 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
                 (!addend2 || (ld_addend2 % 4 == 0 && out_aligned(addend2, sbf)));
     g.bn_partial = nullptr;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
-    g.tiles_x = g.tiles_img = 0;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
-    if (sbf)
-        hipLaunchKernelGGL(k_conv_s2dgrad3<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
-                           static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
+    const unsigned char* wi = static_cast<const unsigned char*>(wt_image);
+    if (sbf && rect)
+        hipLaunchKernelGGL((k_conv_s2dgrad3<true, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy, wi, dx, g, addend, addend2);
+    else if (sbf)
+        hipLaunchKernelGGL((k_conv_s2dgrad3<true, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy, wi, dx, g, addend, addend2);
+    else if (rect)
+        hipLaunchKernelGGL((k_conv_s2dgrad3<false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy, wi, dx, g, addend, addend2);
     else
-        hipLaunchKernelGGL(k_conv_s2dgrad3<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, dy,
-                           static_cast<const unsigned char*>(wt_image), dx, g, addend, addend2);
+        hipLaunchKernelGGL((k_conv_s2dgrad3<false, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, dy, wi, dx, g, addend, addend2);
     SNN_CHECK_LAUNCH("snn_conv3x3_s2_dgrad");
     return 0;
 }

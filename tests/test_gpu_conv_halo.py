@@ -240,7 +240,11 @@ S2_CASES = [
     (3, 9, 11, 64, 32),       # odd sizes, one K chunk
     (2, 1, 1, 64, 64),        # one-pixel images
     (2, 2, 2, 64, 64),        # even size 2: dx pixels (1, .) only reach dy row 0 through kh = 2
-    (1, 17, 310, 64, 64),     # the widest supported dy row (Wo = 155, PW = 156)
+    (1, 17, 310, 64, 64),     # the widest dy row of the strip form (Wo = 155, PW = 156)
+    # wider rows: 4 x 32 rectangles of dy cells of one image
+    (2, 21, 330, 64, 64),     # Wo = 165 (5 rectangles + a partial one), Ho = 11 (partial bottom rectangle), odd input height
+    (1, 90, 640, 64, 32),     # a 1 Mpx stage entry (180x320 dy would be the real one): even sizes, one K chunk
+    (2, 7, 641, 128, 96),     # odd width 641 -> Wo = 321: the last dx column comes from kw = 1 only; three K chunks
 ]
 
 
