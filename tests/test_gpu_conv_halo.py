@@ -364,3 +364,51 @@ def test_deferred_batchnorm_apply_in_bottleneck_layers_is_bit_identical(H_):
     assert res[True][2].count("snn_conv3x3_halo_bn") == 3 and res[True][2].count("snn_bn_bwd_apply") == 0
     assert res[False][2].count("snn_conv3x3_halo_bn") == 0 and res[False][2].count("snn_bn_bwd_apply") == 3
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
+def test_staging_passes_without_memory_access_do_not_break_the_counted_weight_dma_wait(H_):
+    """Regression (round 3): the k-step's ``s_waitcnt vmcnt(1)`` ("all but the youngest operation have landed" = the
+    weight tile's LDS-DMA is complete) is only valid when the youngest operation - the staging pass of the next chunk - is
+    a real memory access.  A pass whose lanes are all out of range is answered at once, AHEAD of the older DMA; the next tap
+    then multiplied the previous weight tile on some tiles, differently from run to run.  It showed on the rectangle form
+    of the stride-2 kernel at sizes with many tiles in flight (passes 6-8 lie outside its 165-cell halo); those steps now
+    issue no load and drain the queue.  Same-size check: run-to-run equality and equality with the four-launch implicit
+    GEMM (both are bf16 x 3 with the same products: the sums agree to fp32 rounding)."""
+    _hip = H_
+    st = torch.cuda.current_stream().cuda_stream
+    N, H, W, Cin, Cout = 16, 360, 640, 64, 128
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    torch.manual_seed(0)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda") / (9 * Cin) ** 0.5
+    gy = torch.randn(N, Ho, Wo, Cout, device="cuda")
+    wt = torch.empty(Cin, 3, 3, Cout, device="cuda")
+    _hip.call("snn_weight_transpose", w.data_ptr(), wt.data_ptr(), Cout, 3, 3, Cin, st)
+    img = _image(_hip, wt, Cin, Cout, 1, _hip.PREC_BF16X3)
+    ref = torch.empty(N, H, W, Cin, device="cuda")
+    _hip.call("snn_conv2d_dgrad", gy.data_ptr(), Cout, wt.data_ptr(), None, ref.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout, 3, 3,
+              2, 1, None, 0, None, 0, _hip.PREC_BF16X3, st)
+    outs = []
+    for _ in range(3):
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        _hip.call("snn_conv3x3_s2_dgrad", gy.data_ptr(), Cout, img.data_ptr(), dx.data_ptr(), Cin, N, H, W, Cin, Ho, Wo, Cout,
+                  None, 0, None, 0, _hip.PREC_BF16X3, st)
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float((outs[0] - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # the stride-1 kernel on rectangles (its passes 7-8 lie outside the 204-cell halo) and on strips whose pad rows hold
+    # whole passes (W + 1 = 77 cells): run-to-run equality at a size with many tiles in flight
+    for (n, h, ww, ci, co) in ((32, 120, 152, 32, 32), (160, 60, 76, 64, 64)):
+        x = torch.randn(n, h, ww, ci, device="cuda")
+        wk = torch.randn(co, 3, 3, ci, device="cuda") / (9 * ci) ** 0.5
+        im = _image(_hip, wk, co, ci, 0, _hip.PREC_FP16X3)
+        ys = []
+        for _ in range(3):
+            y = torch.full((n, h, ww, co), float("nan"), device="cuda")
+            _hip.call("snn_conv3x3_halo", x.data_ptr(), ci, im.data_ptr(), y.data_ptr(), co, n, h, ww, ci, co, None, 0, None, 0,
+                      None, 0, None, _hip.PREC_FP16X3, st)
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+        yg = torch.empty_like(ys[0])
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), ci, wk.data_ptr(), None, yg.data_ptr(), co, n, h, ww, ci, h, ww, co, 3, 3, 1, 1,
+                  None, 0, None, 0, None, _hip.PREC_BF16X6, st)
+        assert rel_err(ys[0], yg) < 2e-6
