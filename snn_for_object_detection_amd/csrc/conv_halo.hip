@@ -428,11 +428,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);       // not above the MFMAs: its wait would expose this tap's DMA
                 if (tap >= 1) bn_combine(pf[pp], pfy[pp & 1], pp, more ? (chunk + 1) * 32 : 0, more);
                 __builtin_amdgcn_sched_barrier(0);
-                // (counted only while this tap's and the previous tap's passes are real memory accesses - see live_passes)
-                const bool counted = pass_live && (tap == 0 || ((live_passes >> (tap - 1)) & 1u));
-                if (!counted) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else if (tap >= 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // (this variant drains the queue: besides the two loads it also queues the dy STORE of the previous pass, which
+                // is out of range - answered at once, see live_passes - for every pass outside the tile's own cells, so a
+                // counted wait cannot tell whether the weight DMA has landed.  The variant is off by default.)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else if constexpr (ABL & 2) asm volatile("" ::: "memory");
             else if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (pass_live) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
