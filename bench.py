@@ -488,6 +488,16 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if args.config == "gen1" and (H, W, classes) == (cfg["H"], cfg["W"], cfg["classes"]):
+            # whole-step view against BASELINE.md section 2 (ideal-fusion byte model of this network: 114.0 M tensor elements
+            # moved per event-frame fwd + bwd): 456.1 MB per frame with fp32 tensors, 228.0 MB with bf16 tensors, at 8 TB/s
+            per_frame = 228.0e6 if sb else 456.1e6
+            roof = PEAK_HBM_GBS * 1e9 / per_frame
+            out["step_roofline"] = {"bound": "hbm", "ideal_bytes_per_frame": per_frame,
+                                    "roof_frames_per_s_per_gpu": roof, "achieved_frames_per_s_per_gpu": frames_per_s / world,
+                                    "frac": frames_per_s / world / roof,
+                                    "basis": "BASELINE.md section 2: ideal-fusion bytes per event-frame ("
+                                             + ("bf16" if sb else "fp32") + " tensors) at the 8 TB/s HBM3E spec"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
