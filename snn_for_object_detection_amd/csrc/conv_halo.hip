@@ -246,19 +246,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
         }
     }
 
-    // passes of which at least one lane of THIS WAVE reads real memory (wave-uniform).  The counted wait of a k-step
-    // ("everything but the youngest operation has landed") is only valid when that youngest operation is a real memory
-    // access queued behind the weight DMA: a load whose lanes are ALL out of range (a pass inside a pad row, past the last
-    // image, outside the rectangle halo; every pass when there is no next chunk) is answered at once, ahead of the older
-    // DMA, and the count is met with the DMA still in flight - the next tap then multiplies the previous weight tile
-    // (found on the rectangle form of the stride-2 kernel: sporadic tiles, run-to-run different).  Such steps issue no
-    // load and drain the queue instead.
-    unsigned live_passes = 0;
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-        live_passes |= (__builtin_amdgcn_ballot_w64(voff[p] < 0x80000000u) != 0ull ? 1u : 0u) << p;
-    live_passes = __builtin_amdgcn_readfirstlane(live_passes);
-
+    // The wait that closes a k-step DRAINS the vector-memory queue (vmcnt(0)).  Rounds 3's first form counted instead
+    // ("vmcnt(1): everything but the youngest operation - the staging pass of the next chunk - has landed, so the weight tile's
+    // LDS-DMA is complete") to leave that pass in flight for a second k-step.  The count is only valid while the youngest
+    // operation really completes behind the older DMA, and a buffer load whose lanes are ALL out of range (a pass inside a pad
+    // row, past the last image, outside a rectangle's halo; every pass when there is no next chunk) is answered at once: the
+    // count was met with the DMA still in flight and the next tap multiplied the PREVIOUS weight tile - on a few tiles per
+    // launch, differently from run to run (found on the rectangle form of the stride-2 kernel at 1 Mpx).  Whether a pass
+    // that hits in cache can overtake the DMA in the same way is not something to bet results on: draining costs 3 % on the
+    // two-chunk 64-channel layers (193 -> 198 us) and nothing elsewhere.
     // ---- fragment addressing
     int cellbase[TM];
 #pragma unroll
@@ -405,11 +401,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             if constexpr (!(ABL & 1))
                 if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            // one staging pass of the next chunk's halo per tap: it is YOUNGER than this step's LDS-DMA, so the
-            // counted wait below leaves it in flight for a whole k-step (out-of-range offsets when there is no next chunk)
-            const bool pass_live = more && ((live_passes >> tap) & 1u);
+            // one staging pass of the next chunk's halo per tap (none when there is no next chunk)
             if constexpr (!(ABL & 4)) {
-                if (BNAP || pass_live) pf[tap] = load_pass(more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u);
+                if (BNAP || more) pf[tap] = load_pass(more ? (int)(voff[tap] + (unsigned)cbytes) : (int)0x80000000u);
             }
             if constexpr (BNAP)
                 pfy[tap & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -417,8 +411,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
             kstep((kh - 1) * pitch + (kw - 1), Bimg + cur * BTILE);
-            // this wave's share of the next weight tile has landed (all but the youngest vector-memory operation are
-            // done); the barrier makes every wave's share visible and retires this step's reads of the current buffer
+            // this wave's share of the next weight tile has landed (the queue is drained, see above); the barrier makes every
+            // wave's share visible and retires this step's reads of the current buffer
             // (lgkmcnt(0): this wave's fragment reads have really left the LDS before another wave may overwrite them)
             if constexpr (BNAP) {
                 // the pass requested during the PREVIOUS tap has landed (it is older than this tap's weight DMA, which this
@@ -429,12 +423,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                 if (tap >= 1) bn_combine(pf[pp], pfy[pp & 1], pp, more ? (chunk + 1) * 32 : 0, more);
                 __builtin_amdgcn_sched_barrier(0);
                 // (this variant drains the queue: besides the two loads it also queues the dy STORE of the previous pass, which
-                // is out of range - answered at once, see live_passes - for every pass outside the tile's own cells, so a
+                // is out of range - answered at once, see above - for every pass outside the tile's own cells, so a
                 // counted wait cannot tell whether the weight DMA has landed.  The variant is off by default.)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else if constexpr (ABL & 2) asm volatile("" ::: "memory");
             else if constexpr (ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (pass_live) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (more) {   // every wave is past its last read of this chunk's halo image: swap in the next one
@@ -641,11 +634,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
         voff[p] = ok ? (unsigned)((pix * g.ldx + quad * 4) * ES) : 0x80000000u;
         awr[p] = cell_slot_off(cell, quad >> 1) + (quad & 1) * 8;
     }
-    unsigned live_passes = 0;   // passes with a real memory access in this wave: see k_conv_halo3
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-        live_passes |= (__builtin_amdgcn_ballot_w64(voff[p] < 0x80000000u) != 0ull ? 1u : 0u) << p;
-    live_passes = __builtin_amdgcn_readfirstlane(live_passes);
     const int cellbase = RECT ? wave * SPITCH + r : wave * 32 + r;
     const int nchunks = g.Cin >> 5;
     const int co_tiles = g.Cout >> 5;
@@ -731,21 +719,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
             const int cur = kk & 1;
             if (kk + 1 < nk) dma_b(kk + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            // A staging pass of the next chunk's halo rides behind this step's weight DMA, and the counted wait below
-            // (vmcnt(1): everything but the youngest operation has landed) relies on that pass being a REAL memory access: a
-            // load whose lanes are all out of range returns at once, ahead of the older DMA, and the count is met with the
-            // DMA still in flight (seen on the rectangle form, whose passes 6-8 lie outside its 165-cell halo: taps 6 and 8
-            // multiplied a stale weight tile on some tiles).  Such steps issue no load and drain the queue instead.
-            const bool pass_live = more && ((live_passes >> tap) & 1u);
-            if (pass_live) pf[tap] = load_pass((int)(voff[tap] + (unsigned)cbytes));
+            // one staging pass of the next chunk's halo per tap; the wait below drains the queue (see k_conv_halo3: a counted
+            // wait is not valid behind a pass whose lanes are all out of range - this kernel's rectangle form showed it)
+            if (more) pf[tap] = load_pass((int)(voff[tap] + (unsigned)cbytes));
             __builtin_amdgcn_sched_barrier(0);
             const int kh = tap / 3, kw = tap - 3 * kh;
             // kh = 1: even dx rows, dy row a; kh = 0: odd rows, dy row a + 1; kh = 2: odd rows, dy row a (columns alike)
             const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
             const int dh = kh == 0 ? 1 : 0, dw = kw == 0 ? 1 : 0;
             kstep(dh * pitch + dw, Bimg + cur * BTILE, acc[2 * ph + pw]);
-            if (pass_live) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (more) {
             store_halo();
