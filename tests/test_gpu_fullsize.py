@@ -42,7 +42,7 @@ def test_fullsize_step_is_deterministic(S):
     T, B, H, W = 32, 5, 240, 304
     X, labels = synthetic_events(T, B, H, W, p=0.05).cuda(), synthetic_labels(B).cuda()
     results = []
-    for _ in range(2):
+    for _ in range(5):   # (five runs: a race that loses once in a few thousand tiles shows here - see DESIGN section 5)
         torch.manual_seed(2)
         model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
         tr = FlatTrainer(model)
@@ -52,8 +52,9 @@ def test_fullsize_step_is_deterministic(S):
         tr.synchronize()
         results.append((loss.detach().clone(), tr.flat_grad.clone()))
         del model, tr
-    assert torch.equal(results[0][0], results[1][0])
-    assert torch.equal(results[0][1], results[1][1])
+    for r in results[1:]:
+        assert torch.equal(results[0][0], r[0])
+        assert torch.equal(results[0][1], r[1])
     g = results[0][1]
     assert torch.isfinite(g).all() and g.abs().max() > 0
 
