@@ -167,12 +167,13 @@ int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ld
                         const float* coef, int T, int frames_per_step, float* dw, int64_t N, int H, int W, int Cin, int Ho,
                         int Wo, int Cout, int KH, int KW, int stride, int pad, int accumulate, float* workspace, int splitk,
                         void* stream);
-/* ---- Halo-resident 3x3 / stride 1 / pad 1 convolution (csrc/conv_halo.hip): forward AND data gradient of the 64- and
+/* ---- Halo-resident 3x3 / stride 1 / pad 1 convolution (csrc/conv_halo.hip): forward AND data gradient of the 32-, 64- and
  * 128-channel layers (reference models/modules/layer_gen.py:129-136, nn.Conv2d(C, C', 3, padding=1, bias=False)).
  * The activation halo of a tile is fetched and split into its 16-bit pieces once per 32-channel chunk (the implicit
  * GEMM does both once per tap); the weights arrive by LDS-DMA from an image in MFMA-fragment order.
- *   snn_conv3x3_halo_supported : 1 when the kernel covers the shape (Cin % 32 == 0, Cout % 64 == 0, W <= 78, ...);
- *                                otherwise use snn_conv2d_fwd / snn_conv2d_dgrad.
+ *   snn_conv3x3_halo_supported : 1 when the kernel covers the shape (Cin % 32 == 0; Cout = 32 or a multiple of 64; rows of
+ *                                up to 78 pixels as padded strips, longer rows as 4 x 32 rectangles); otherwise use
+ *                                snn_conv2d_fwd / snn_conv2d_dgrad.
  *   snn_weight_frag_image_batched : builds the weight images of n layers in ONE launch.  table (device, int64) rows
  *       {float offset of the layer's [O][3][3][I] matrix in flat_src, BYTE offset of its image in flat_dst, O, I}; an
  *       image takes snn_weight_frag_image_bytes(O, I) = 9*O*I*4 bytes (as many as the weights); max_threads = the
@@ -187,7 +188,8 @@ int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx, int64_t ld
  * four stride-phase classes of dx are produced from one staged dy halo instead of four launches that each gather dy
  * again.  wt_image = the layer's data-gradient image (snn_weight_frag_image_batched of the transposed weights, flip = 1,
  * SNN_PREC_BF16X3 - the image the stride-1 data gradient uses).  dx[N][H][W][lddx] (Cin channels) from dy[N][Ho][Wo][lddy]
- * (Cout channels), Ho = (H-1)/2 + 1; addend / addend2 as for snn_conv2d_dgrad.  bf16 x 3 arithmetic, or bf16 storage. */
+ * (Cout channels), Ho = (H-1)/2 + 1; addend / addend2 as for snn_conv2d_dgrad.  bf16 x 3 arithmetic, or bf16 storage.
+ * Covers Cout % 32 == 0, Cin % 64 == 0, any width (dy rows of up to 157 cells as padded strips, longer ones as rectangles). */
 int snn_conv3x3_s2_dgrad_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout);
 int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* wt_image, float* dx, int64_t lddx, int64_t N, int H, int W,
                          int Cin, int Ho, int Wo, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
