@@ -11,6 +11,16 @@
 #include <type_traits>
 #include "snn_common.h"
 
+#ifdef SNN_TUNING
+// tuning builds only: timing experiments on the reverse scan's BatchNorm sums (WRONG results): bit 0 no LDS accumulation,
+// bit 1 no shuffles either, bit 2 no slab zeroing / write-out
+__device__ int g_bwd_abl = 0;
+extern "C" int snn_debug_set_bwd_abl(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_abl), &v, sizeof(int)); }
+#define BWD_ABL(bit) ((g_bwd_abl >> (bit)) & 1)
+#else
+#define BWD_ABL(bit) 0
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -471,6 +481,44 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
     }
 }
 
+// value of the partner lane l ^ 32 (valid in the UPPER 32 lanes) / l ^ 16 (valid in the odd 16-lane rows)
+__device__ __forceinline__ float swap32_partner(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(u, u, false, false)[0]);
+}
+__device__ __forceinline__ float swap16_partner(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(u, u, false, false)[0]);
+}
+
+// Wave-level combine of the per-thread BatchNorm partial sums: lanes l and l ^ stride (stride a multiple of cvb)
+// hold the same channels.  The two wide strides go through the permute-swap VALU instructions of gfx950
+// (v_permlane32_swap / v_permlane16_swap) instead of ds_bpermute shuffles - one dependent LDS round trip per value and
+// stride less in a latency-bound scan (36 -> 30.5 us on the 19x15 and 10x8 maps).  The sum therefore ends up in the
+// TOP lanes of the wave (row 3, or the upper half when cvb = 32): wave_sum_owner() names them.  Both reverse scans use
+// this pair, so their sums associate identically (the checkpointed scan is tested bit-equal to the plain one).
+template <int VEC>
+__device__ __forceinline__ void wave_sum_channels(float (&s1)[VEC], float (&s2)[VEC], int cvb) {
+    if (cvb >= 64) return;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        s1[j] += swap32_partner(s1[j]);
+        s2[j] += swap32_partner(s2[j]);
+        if (cvb < 32) {
+            s1[j] += swap16_partner(s1[j]);
+            s2[j] += swap16_partner(s2[j]);
+        }
+        for (int stride = cvb; stride < 16; stride <<= 1) {   // (inside a 16-lane row)
+            s1[j] += __shfl_xor(s1[j], stride, 64);
+            s2[j] += __shfl_xor(s2[j], stride, 64);
+        }
+    }
+}
+__device__ __forceinline__ bool wave_sum_owner(int lane, int cvb) {
+    const int own_lo = cvb >= 32 ? 64 - cvb : 48;   // (cvb >= 64: every lane owns its channels)
+    return cvb >= 64 || (lane >= own_lo && lane < own_lo + cvb);
+}
+
 // ------------------------------------------------------------------------------------------
 // Backward (reverse-time) scan with per-(t,c) partial sums for the BatchNorm backward.
 // grid = (GX pixel groups, GY channel blocks).  A thread owns NP pixels x VEC channels; per timestep it
@@ -574,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
     const bool lane_ok = (ps < P) && (cg < cv);
     const int c = lane_ok ? cg * VEC : 0;
     const int wave = tid >> 6;
-    if (MODE != 0) {
+    if (MODE != 0 && !BWD_ABL(2)) {
         const int n = (MODE == 1 ? kWaves : 1) * T * cb * 2;
         for (int k = tid; k < n; k += kThreads) red[k] = 0.0f;
         __syncthreads();
@@ -782,16 +830,8 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     VecS<VEC, SB>::store(gx, row * C + c, g);
             }
             if (MODE == 1) {
-                // lanes l and l ^ stride (stride a multiple of cvb) hold the same channels
-                if (cvb < 64) {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        for (int stride = cvb; stride < 64; stride <<= 1) {
-                            s1[j] += __shfl_xor(s1[j], stride, 64);
-                            s2[j] += __shfl_xor(s2[j], stride, 64);
-                        }
-                }
-                if ((cvb >= 64 || (tid & 63) < cvb) && lane_ok) {
+                if (!BWD_ABL(1)) wave_sum_channels<VEC>(s1, s2, cvb);
+                if (wave_sum_owner(tid & 63, cvb) && lane_ok && !BWD_ABL(0)) {
                     float* r = red + (((int64_t)wave * T + t) * cb + cgl * VEC) * 2;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -862,7 +902,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             }
         }
     }
-    if (MODE != 0) {
+    if (MODE != 0 && !BWD_ABL(2)) {
         __syncthreads();
         // sums[bx][t][c][2], stored as fp32 (the block sums ARE fp32; doubles would only double the bytes the
         // finalize kernel reads back: up to 512 x T x C x 2 values per layer)
@@ -1033,15 +1073,8 @@ __global__ __launch_bounds__(kThreads) void k_lif_bwd_ckpt(
                     Vec<VEC>::store(gx + row * C + c, g);
                 }
                 if (MODE == 1) {
-                    if (cvb < 64) {
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j)
-                            for (int stride = cvb; stride < 64; stride <<= 1) {
-                                s1[j] += __shfl_xor(s1[j], stride, 64);
-                                s2[j] += __shfl_xor(s2[j], stride, 64);
-                            }
-                    }
-                    if ((cvb >= 64 || (tid & 63) < cvb) && lane_ok) {
+                    wave_sum_channels<VEC>(s1, s2, cvb);
+                    if (wave_sum_owner(tid & 63, cvb) && lane_ok) {
                         float* r = red + (((int64_t)wave * T + t) * cb + cgl * VEC) * 2;
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) {
