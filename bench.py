@@ -203,6 +203,29 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd)
 
 
+_JSON_FD = None
+
+
+def reserve_stdout() -> None:
+    """Keep file descriptor 1 for the ONE JSON line: everything else any library writes to stdout during the run goes to
+    stderr instead (RCCL prints a five-line version banner on stdout when its communicator comes up - rank 0's stdout
+    then no longer parses as a JSON line)."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj) -> None:
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_JSON_FD, line)
+
+
 def dry_run(args, world: int, rank: int) -> None:
     """The multi-process control flow without a GPU: rendezvous, one all-reduce, the rank-0 JSON line."""
     import torch.distributed as dist
@@ -217,9 +240,9 @@ def dry_run(args, world: int, rank: int) -> None:
         seen = int(t.item())
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd", "value": None,
-                          "unit": "event-frames/s", "n_gpus": world, "dry_run": True,
-                          "dist": {"backend": backend, "world_size": world, "ranks_in_allreduce": seen}}))
+        emit_json({"metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd", "value": None,
+                   "unit": "event-frames/s", "n_gpus": world, "dry_run": True,
+                   "dist": {"backend": backend, "world_size": world, "ranks_in_allreduce": seen}})
     if world > 1:
         dist.destroy_process_group()
 
@@ -251,6 +274,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="N=1 only: initialise the process group (RCCL unless SNN_DIST_BACKEND says otherwise) with ONE rank "
+                         "and keep every collective of the N>1 step in the timed region - a rehearsal of the RCCL plumbing "
+                         "on a one-GPU box, labelled as such in the JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launch / rendezvous / collective control flow only: no GPU work, no timing; "
                          "the JSON line carries n_gpus and dist but value null (CPU boxes, SNN_DIST_BACKEND=gloo)")
@@ -277,6 +304,7 @@ def main():
     if args.gpus != world:
         # never measure a different number of GPUs than the one asked for (the line would carry the wrong n_gpus)
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    reserve_stdout()
     if args.dry_run:
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
@@ -288,8 +316,16 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     backend = None
-    if world > 1:
+    distributed = world > 1 or args.rehearse_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --rehearse-dist without a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL ("nccl") over xGMI is the production transport; SNN_DIST_BACKEND=gloo exists only to rehearse the
         # multi-process control flow on a box with fewer GPUs than ranks
         backend = os.environ.get("SNN_DIST_BACKEND", "nccl")
@@ -331,9 +367,9 @@ def main():
             return model.training_step((X, labels))
         lr = model.hparams.learning_rate
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    trainer = FlatTrainer(model, lr=lr)
+    trainer = FlatTrainer(model, lr=lr, exchange_single_rank=args.rehearse_dist)
     broadcast_parameters(trainer)
-    if args.sync_bn and world > 1:
+    if args.sync_bn and distributed:
         from snn_for_object_detection_amd.trainer import convert_sync_batchnorm
         convert_sync_batchnorm(model)
 
@@ -349,7 +385,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -359,14 +395,14 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
     frames_per_s = world * B * T * steps / elapsed
     replicas_equal = None
-    if world > 1:
+    if distributed:
         # evidence that the gradient exchange kept the replicas together: after `warmup + steps` updates every rank
         # holds the same weights (ranks saw different shards, so a missing or partial all-reduce would show here)
         chk = trainer.flat_param.double().abs().sum().reshape(1)
@@ -427,7 +463,7 @@ def main():
         threads = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
         cpu = cpu_baseline(args.config, H, W, classes, threads, cfg["p"])  # bounded sample: about 10-30 s of CPU work
 
-    if world > 1:
+    if distributed:
         dist.barrier()
     if rank == 0:
         exact = args.forward_precision == "fp32" and args.backward_precision == "fp32"
@@ -459,7 +495,7 @@ def main():
                             + " + BPTT bwd + flat-grad all-reduce (N>1) + fused Adamax",
                 "name": args.config, "trainable_params": n_params,
                 "global_batch": B * world, "timesteps": T, "parallelism": f"dp{world}",
-                "sync_batchnorm": bool(args.sync_bn and world > 1),
+                "sync_batchnorm": bool(args.sync_bn and distributed),
                 "storage": args.storage,
                 "arithmetic": "bf16 STORAGE of the activation tensors (conv outputs, spikes, saved potentials, gradients), "
                               "fp32 neuron state / BatchNorm statistics / weights / accumulation; convolutions: stored bf16 "
@@ -483,8 +519,13 @@ def main():
                                            "hook at the backbone / neck boundary (overlaps the backbone's backward "
                                            "pass), backbone part in step()" if getattr(trainer, "_early_lo", None)
                                            else "one SUM all-reduce of the flat fp32 gradient per step")
-                     if world > 1 else None,
-                     "replicas_equal_after_run": replicas_equal},
+                     if distributed else None,
+                     "replicas_equal_after_run": replicas_equal,
+                     # (device, candidates probed, runs beside the main stream?) for the weight-gradient and the
+                     # communication stream: HIP streams share a few hardware queues, see functional.concurrent_stream
+                     "side_streams_probed": S.functional._STREAM_PROBE_LOG,
+                     **({"rehearsal": "one-rank process group: every collective of the N>1 step is issued, none moves data "
+                                      "between GPUs"} if args.rehearse_dist and world == 1 else {})},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
@@ -498,8 +539,8 @@ def main():
                                     "frac": frames_per_s / world / roof,
                                     "basis": "BASELINE.md section 2: ideal-fusion bytes per event-frame ("
                                              + ("bf16" if sb else "fp32") + " tensors) at the 8 TB/s HBM3E spec"}
-        print(json.dumps(out))
-    if world > 1:
+        emit_json(out)
+    if distributed:
         dist.destroy_process_group()
 
 

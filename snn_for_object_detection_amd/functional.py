@@ -136,10 +136,57 @@ _SIDE_STREAMS = {}
 USE_WGRAD_STREAM = not os.environ.get("SNN_NO_WGRAD_STREAM")   # tuning aid: everything on one stream
 
 
+# HIP multiplexes its streams onto a few hardware queues (four by default), in the order the streams are first used.  Two
+# streams that land on ONE queue run strictly one after the other: with an RCCL communicator created before the model
+# (the normal order under torchrun) the weight-gradient stream shared the main stream's queue and the step lost the whole
+# overlap - 25.9 instead of 24.7 ms, measured with a one-rank RCCL group (tools/dist_overhead.py).  So a side stream is
+# not taken blindly from torch's pool: candidates are PROBED against the stream they are meant to run beside.
+STREAM_PROBE_CANDIDATES = 12
+_STREAM_PROBE_LOG = []   # (device, candidates tried, concurrent?) per chosen stream - bench.py reports it
+
+
+def runs_concurrently(candidate: "torch.cuda.Stream", beside: "torch.cuda.Stream") -> bool:
+    """True if work queued on ``candidate`` AFTER a long-running job on ``beside`` finishes before that job does (the two
+    do not share a hardware queue).  Synchronises the device; about 2 ms."""
+    dev = beside.device
+    torch.cuda.synchronize(dev)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MiB: eight fills are about a millisecond
+    small = torch.empty(64, dtype=torch.float32, device=dev)
+    e0, e1, c1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(beside):
+        big.fill_(0.0)                                                # first-touch cost stays outside the timed part
+        e0.record(beside)
+        for _ in range(8):
+            big.fill_(1.0)
+        e1.record(beside)
+    with torch.cuda.stream(candidate):
+        small.fill_(1.0)
+        c1.record(candidate)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(c1) < 0.5 * e0.elapsed_time(e1)
+
+
+def concurrent_stream(beside: "torch.cuda.Stream", avoid=()) -> "torch.cuda.Stream":
+    """A stream of ``beside``'s device that really runs beside it (and is none of ``avoid``): the first probed candidate
+    from torch's pool that does; the first candidate if none does (the result is still correct, only serial)."""
+    dev = beside.device
+    tried = []
+    for _ in range(STREAM_PROBE_CANDIDATES):
+        cand = torch.cuda.Stream(device=dev)
+        if any(cand.cuda_stream == o.cuda_stream for o in tuple(avoid) + tuple(tried) + (beside,)):
+            continue
+        tried.append(cand)
+        if runs_concurrently(cand, beside):
+            _STREAM_PROBE_LOG.append((str(dev), len(tried), True))
+            return cand
+    _STREAM_PROBE_LOG.append((str(dev), len(tried), False))
+    return tried[0] if tried else torch.cuda.Stream(device=dev)
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
     st = _SIDE_STREAMS.get(device)
     if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        st = _SIDE_STREAMS[device] = concurrent_stream(torch.cuda.current_stream(device))
     return st
 
 

@@ -44,7 +44,7 @@ class FlatTrainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = False,
-                 overlap_grad_exchange: bool = True):
+                 overlap_grad_exchange: bool = True, exchange_single_rank: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise RuntimeError("model has no trainable parameters")
@@ -62,6 +62,9 @@ class FlatTrainer:
         self.param_steps: List[int] = [0] * len(self.params)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # whether the step contains the exchange collectives.  ``exchange_single_rank`` keeps them in a one-rank group
+        # (they sum over one rank): a rehearsal of the RCCL plumbing - streams, events, work handles - on a one-GPU box
+        self.exchange = self.world > 1 or (exchange_single_rank and dist.is_available() and dist.is_initialized())
         self.slots: List[GradSlot] = []
         self.grad_views: List[torch.Tensor] = []
         # transposed copies [Cin][KH][KW][Cout] of every conv weight (operand of the data-gradient conv), refreshed
@@ -148,11 +151,17 @@ class FlatTrainer:
         self._flags_work = None
         self._flags = None
         self._ones_flags = None
-        if (overlap_grad_exchange and self.world > 1 and hasattr(model, "_snn_neck_grads_ready")
+        if dev.type == "cuda" and _HF.USE_WGRAD_STREAM:
+            # the weight-gradient stream is chosen NOW, with the device idle (its choice probes hardware-queue sharing)
+            _HF._side_stream(dev)
+        if (overlap_grad_exchange and self.exchange and hasattr(model, "_snn_neck_grads_ready")
                 and all(hasattr(model, a) for a in ("neck_net", "head_net"))):
             # a SODa detector: neck + head gradients go out while the backbone's backward pass still runs
             self.overlap_from([model.neck_net, model.head_net])
             model._snn_neck_grads_ready = self.early_all_reduce
+            if dev.type == "cuda":
+                self._comm_stream = _HF.concurrent_stream(torch.cuda.current_stream(dev),
+                                                          avoid=tuple(_HF._SIDE_STREAMS.values()))
         self.refresh_transposed_weights()
 
     # ------------------------------------------------------------------ overlapped gradient exchange
@@ -176,12 +185,13 @@ class FlatTrainer:
     def early_all_reduce(self) -> None:
         """Start the all-reduce of ``flat_grad[early_lo:]`` on a communication stream behind everything the main and
         the weight-gradient streams hold at this point.  No-op for a single rank or without ``overlap_from``."""
-        if self.world <= 1 or self._early_lo is None or self._early_work is not None:
+        if not self.exchange or self._early_lo is None or self._early_work is not None:
             return
         part = self.flat_grad[self._early_lo:]
         if part.is_cuda:
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=part.device)
+            if self._comm_stream is None:   # (normally taken in __init__, where probing it costs no pipeline drain)
+                self._comm_stream = _HF.concurrent_stream(torch.cuda.current_stream(part.device),
+                                                          avoid=tuple(_HF._SIDE_STREAMS.values()))
             comm = self._comm_stream
             comm.wait_stream(torch.cuda.current_stream())
             for st in _HF._SIDE_STREAMS.values():
@@ -276,7 +286,7 @@ class FlatTrainer:
         """SUM all-reduce of the flat gradient (averaging is folded into the Adamax kernel): ONE collective over the whole
         buffer, or - when ``early_all_reduce()`` already sent the tail during the backward pass - one over the head
         that was still being written then, joined with the early one."""
-        if self.world <= 1:
+        if not self.exchange:
             return
         if self._early_work is not None:
             if self._early_lo > 0:
@@ -295,7 +305,7 @@ class FlatTrainer:
         gradients).  EVERY rank enters the flag exchange in EVERY step (a rank-local condition in front of a collective
         hangs the ranks that took the other branch); only a rank that itself skipped a parameter reads the result."""
         written = [slot.written for slot in self.slots]
-        if self.world > 1:
+        if self.exchange:
             if all(written):
                 # the common case never touches the host: a device-side copy of a cached all-ones vector (building the
                 # tensor from the Python list is a pageable host-to-device copy that stalls the launching thread until
@@ -342,7 +352,7 @@ class FlatTrainer:
 
     def sync_buffers(self, src: int = 0) -> None:
         """Rank ``src``'s BatchNorm buffers to every rank in one broadcast (torch DDP's ``broadcast_buffers``)."""
-        if self.world <= 1 or not (self._float_buffers or self._int_buffers):
+        if not self.exchange or not (self._float_buffers or self._int_buffers):
             return
         flat = torch.cat([b.detach().reshape(-1).float() for b in self._float_buffers]
                          + [b.detach().reshape(-1).float() for b in self._int_buffers])
@@ -464,7 +474,7 @@ def convert_sync_batchnorm(model: torch.nn.Module, process_group=None) -> torch.
 
 def broadcast_parameters(trainer: FlatTrainer, src: int = 0) -> None:
     """Make every rank start from rank ``src``'s weights (DDP does this at construction)."""
-    if trainer.world > 1:
+    if trainer.exchange:
         dist.broadcast(trainer.flat_param, src=src, group=trainer.group)
         if trainer.flat_param.is_cuda:
             trainer.refresh_transposed_weights()  # the weights changed behind torch's version counters

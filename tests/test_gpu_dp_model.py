@@ -181,3 +181,70 @@ def test_a_parameter_written_on_one_rank_only_does_not_hang_the_step(tmp_path, h
     assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 1 and r0["steps"][0] == 2
     # Adamax, first step, gradient 1/2 (ones averaged over two ranks): the update is lr * sign = 1e-2 exactly-ish
     assert torch.allclose(r0["start"] - r0["extra"], torch.full_like(r0["start"], 1e-2), rtol=1e-4, atol=0)
+
+
+def _rccl_worker(rank, world, port, out_dir, sync_bn):
+    """One rank on RCCL ("nccl"), every collective of the N > 1 step issued (``exchange_single_rank``)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
+                            device_id=torch.device("cuda", 0))
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters, convert_sync_batchnorm
+        torch.manual_seed(100)
+        model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+        tr = FlatTrainer(model, lr=1e-3, exchange_single_rank=True)
+        assert tr.exchange and tr._early_lo is not None      # the overlapped exchange is armed
+        broadcast_parameters(tr)
+        if sync_bn:
+            convert_sync_batchnorm(model)
+        X, labels = _shard(0)
+        X, labels = X.cuda(), labels.cuda()
+        losses = []
+        for _ in range(3):
+            tr.zero_grad()
+            loss = model.training_step((X, labels))
+            loss.backward()
+            assert tr._early_work is not None                # the backward hook started the early all-reduce
+            tr.step()
+            losses.append(loss.item())
+        tr.sync_buffers()
+        torch.cuda.synchronize()
+        torch.save({"losses": losses, "after": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                    "backend": dist.get_backend()}, os.path.join(out_dir, "rccl.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sync_bn", [False, True], ids=["rank-local-bn", "sync-bn"])
+def test_one_rank_on_rccl_with_every_collective_issued_equals_the_plain_step(tmp_path, hip_lib, sync_bn):
+    """The production transport (RCCL) has only gloo rehearsals above.  A one-GPU box cannot hold two RCCL ranks, but it
+    can run the N > 1 step's collectives in a ONE-rank RCCL group: broadcast of the weights, the early all-reduce from the
+    backward hook on the communication stream, the written-flag MAX all-reduce, the head all-reduce, the SyncBatchNorm
+    exchanges, the buffer broadcast.  Sums over one rank change nothing, so three steps must equal the plain
+    single-process run bit for bit - what this pins is the stream / event / work-handle plumbing under ProcessGroupNCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import snn_for_object_detection_amd as S
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), sync_bn), nprocs=1, join=True)
+    got = torch.load(os.path.join(tmp_path, "rccl.pt"))
+    assert got["backend"] == "nccl"
+    torch.manual_seed(100)
+    model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+    tr = FlatTrainer(model, lr=1e-3)
+    X, labels = _shard(0)
+    X, labels = X.cuda(), labels.cuda()
+    losses = []
+    for _ in range(3):
+        tr.zero_grad()
+        loss = model.training_step((X, labels))
+        loss.backward()
+        tr.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    assert got["losses"] == losses
+    for k, v in model.state_dict().items():
+        assert torch.equal(got["after"][k], v.detach().cpu()), k
