@@ -450,6 +450,14 @@ def main():
             "share_of_kernel_time": row["ms"] / total_ms,
             "flops_per_launch": row["flops"] / row["calls"],
             "all_kernels_ms_per_step": total_ms / 2,
+            # every kernel family above 2 % of the kernel time against BOTH roofs (algorithmic work of its launches / their
+            # time): the step is a long tail, no family holds a quarter of it
+            "kernels": [
+                {"kernel": k, "ms_per_step": r["ms"] / 2, "share": r["ms"] / total_ms, "launches_per_step": r["calls"] // 2,
+                 "tflops": r["tflops"], "gbs": r["gbs"], "frac_hbm": r["gbs"] / PEAK_HBM_GBS,
+                 "frac_mfma": (r["tflops"] / mfma_peak_for(k, args.forward_precision, args.backward_precision)[0]
+                               if k.startswith("k_conv") else None)}
+                for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if r["ms"] / total_ms >= 0.02],
             "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream off",
         }
         if args.kernel_table:

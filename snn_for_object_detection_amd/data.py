@@ -24,7 +24,10 @@ class EventBatcher:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("EventBatcher: a HIP device is required (no CPU fallback)")
-        self._copy_stream = torch.cuda.Stream(device=self.device)
+        # a stream that really runs beside the main stream (HIP streams share a few hardware queues: functional.concurrent_stream)
+        from . import functional as _HF
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self._copy_stream = _HF.concurrent_stream(torch.cuda.current_stream(dev), avoid=tuple(_HF._SIDE_STREAMS.values()))
 
     def __call__(self, samples: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, int]],
                  labels: Optional[Sequence[torch.Tensor]] = None):

@@ -1296,6 +1296,11 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
         if bn.momentum is None:
             raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
         momentum = bn.momentum
+        if training and seq.shape[1] * seq.shape[3] * seq.shape[4] <= 1:
+            # torch.nn.functional.batch_norm's own check (the reference's per-timestep BatchNorm2d raises it): one value
+            # per channel has no variance to normalise with
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"{torch.Size((seq.shape[1], seq.shape[2], seq.shape[3], seq.shape[4]))}")
         if training and bn.num_batches_tracked is not None:
             if _NBT_BATCH is not None:
                 _NBT_BATCH.append((bn.num_batches_tracked, int(seq.shape[0])))  # one fused update per forward

@@ -56,9 +56,38 @@ def test_tiny_yolo_train_step_with_random_start_time_matches_oracle(S):
     assert seen == {15, 12, 8}
 
 
-def _train_step_vs_oracle(S, T, B, H, W, pad_rows=0, time_window=0, draw_seed=None, expect_T=None):
+@pytest.mark.parametrize("T,B,H,W,silent", [(3, 3, 33, 47, None), (1, 2, 32, 48, None), (4, 2, 40, 56, 1), (2, 2, 17, 19, None)],
+                         ids=["odd-frame-33x47-B3", "single-timestep", "one-sample-without-events", "smallest-frame-17x19"])
+def test_tiny_yolo_train_step_on_ragged_and_degenerate_inputs_matches_oracle(S, T, B, H, W, silent):
+    """Shapes no tile divides (33x47 and 17x19 frames: every stride-2 stage has an odd extent, the deepest maps are 2x2
+    and 1x1 - partial tiles, halo rows outside the image, one-pixel BatchNorm populations), an odd batch, a
+    sequence of ONE step (the scans' time loops and their pipelined prefetches run zero iterations past the first) and
+    a sample whose frames hold no event at all (constant channels: zero-variance BatchNorm statistics for that sample's
+    share) - the full training step against the oracle, same tolerances as everywhere."""
+    _train_step_vs_oracle(S, T, B, H, W, silent_sample=silent)
+
+
+def test_single_value_batchnorm_population_raises_like_the_reference(S):
+    """B=1 on a 17x19 frame: the deepest map is 1x1, its train-mode BatchNorm sees ONE value per channel and step -
+    ``torch.nn.functional.batch_norm`` (the reference's Norm layer) raises ValueError; so does this path, with its words."""
+    product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=0)
+    X, labels = synthetic_events(2, 1, 17, 19, p=0.08), synthetic_labels(1)
+    product.train()
+    oracle.train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training") as ref:
+        oracle.training_step((X, labels))
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training") as got:
+        product.training_step((X.cuda(), labels.cuda()))
+    assert str(got.value) == str(ref.value)
+    product.eval()                                   # eval mode normalises with the running statistics: no error
+    product(X.cuda())
+
+
+def _train_step_vs_oracle(S, T, B, H, W, pad_rows=0, time_window=0, draw_seed=None, expect_T=None, silent_sample=None):
     product, oracle = make_pair(S.TinyYolo, num_classes=2, time_window=time_window)
     X, labels = synthetic_events(T, B, H, W, p=0.08), synthetic_labels(B, pad_rows=pad_rows)
+    if silent_sample is not None:
+        X[:, silent_sample] = 0.0
     product.train()
     oracle.train()
     if draw_seed is not None:
