@@ -367,7 +367,9 @@ def main():
             return model.training_step((X, labels))
         lr = model.hparams.learning_rate
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    trainer = FlatTrainer(model, lr=lr, exchange_single_rank=args.rehearse_dist)
+    # find_unused_parameters=False is what the reference's `strategy: ddp` means (config/config.yaml:35): every rank
+    # produces every gradient, so the step carries no used-parameter flag exchange
+    trainer = FlatTrainer(model, lr=lr, exchange_single_rank=args.rehearse_dist, find_unused_parameters=False)
     broadcast_parameters(trainer)
     if args.sync_bn and distributed:
         from snn_for_object_detection_amd.trainer import convert_sync_batchnorm

@@ -44,7 +44,8 @@ class FlatTrainer:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, use_grad_slots: bool = True, broadcast_buffers: bool = False,
-                 overlap_grad_exchange: bool = True, exchange_single_rank: bool = False):
+                 overlap_grad_exchange: bool = True, exchange_single_rank: bool = False,
+                 find_unused_parameters: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise RuntimeError("model has no trainable parameters")
@@ -65,6 +66,11 @@ class FlatTrainer:
         # whether the step contains the exchange collectives.  ``exchange_single_rank`` keeps them in a one-rank group
         # (they sum over one rank): a rehearsal of the RCCL plumbing - streams, events, work handles - on a one-GPU box
         self.exchange = self.world > 1 or (exchange_single_rank and dist.is_available() and dist.is_initialized())
+        # torch DDP's switch of the same name.  True: a parameter without a gradient on THIS rank still takes the other
+        # ranks' (one small flag all-reduce per step, as DDP's used-parameter bitmap).  False (what the reference's
+        # ``strategy: ddp`` means, config/config.yaml:35): every rank must produce every gradient in every step - no flag
+        # exchange, and a rank that did not raises before it enters the gradient exchange, as DDP does.
+        self.find_unused_parameters = find_unused_parameters
         self.slots: List[GradSlot] = []
         self.grad_views: List[torch.Tensor] = []
         # transposed copies [Cin][KH][KW][Cout] of every conv weight (operand of the data-gradient conv), refreshed
@@ -305,6 +311,14 @@ class FlatTrainer:
         gradients).  EVERY rank enters the flag exchange in EVERY step (a rank-local condition in front of a collective
         hangs the ranks that took the other branch); only a rank that itself skipped a parameter reads the result."""
         written = [slot.written for slot in self.slots]
+        if self.exchange and not self.find_unused_parameters:
+            if not all(written):
+                missing = [k for k, w in enumerate(written) if not w]
+                raise RuntimeError(f"FlatTrainer(find_unused_parameters=False): {len(missing)} parameter(s) received no "
+                                   f"gradient on this rank in this step (first: index {missing[0]}, shape "
+                                   f"{tuple(self.params[missing[0]].shape)}); build the trainer with "
+                                   "find_unused_parameters=True if parts of the model may stay unused")
+            return written
         if self.exchange:
             if all(written):
                 # the common case never touches the host: a device-side copy of a cached all-ones vector (building the

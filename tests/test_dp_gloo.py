@@ -71,6 +71,17 @@ def _flags_worker(rank, world, port, out_dir):
                 tr._flags_work.wait()
                 tr._flags_work = tr._flags = None
             results.append(tr._written_flags())
+        # find_unused_parameters=False (DDP's default, the reference's `strategy: ddp`): NO collective - calling it on one
+        # rank only must return at once - and a rank with an unwritten parameter raises
+        strict = FlatTrainer(blk, lr=1e-3, find_unused_parameters=False)
+        strict.zero_grad()
+        for slot in strict.slots:
+            slot.written = True
+        if rank == 0:
+            assert strict._written_flags() == [True] * len(strict.slots)
+        strict.slots[1].written = False
+        with pytest.raises(RuntimeError, match="find_unused_parameters=False"):
+            strict._written_flags()
         torch.save(results, os.path.join(out_dir, f"flags{rank}.pt"))
     finally:
         dist.destroy_process_group()

@@ -21,8 +21,14 @@ from snn_for_object_detection_amd.trainer import FlatTrainer  # noqa: E402
 
 
 def shape_of(name, a):
+    if name in ("snn_conv2d_fwd", "snn_conv2d_dgrad"):
+        a = tuple(a[:3]) + tuple(a[4:])   # without the pre-split weight pointer: the positions snn_conv2d_wgrad has
     if name.startswith("snn_conv2d"):
         return f"N{a[5]} {a[6]}x{a[7]} {a[8]}->{a[11]} k{a[12]} s{a[14]}"
+    if name == "snn_conv3x3_halo":
+        return f"N{a[5]} {a[6]}x{a[7]} {a[8]}->{a[9]} {'fwd' if a[17] == 4 else 'dgrad'}{' +add' if a[10] is not None else ''}{' +add2' if a[12] is not None else ''}"
+    if name == "snn_conv3x3_s2_dgrad":
+        return f"N{a[5]} {a[6]}x{a[7]} {a[8]}->{a[11]}"
     if name == "snn_affine_neuron_fwd":
         return f"n{a[0]} T{a[14]} M{a[15]} C{a[16]}{' +shortcut' if a[9] is not None else ''}"
     if name == "snn_affine_neuron_bwd":
