@@ -815,8 +815,8 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
                 a2p = ad2_b + (pix * ld_add2 + n) * ES;
             }
             if (ovec && n + 3 < g.OC) {
-                if (addend) v += St::ld4(a1p, 0);  // fused accumulation
-                if (addend2) v += St::ld4(a2p, 0);
+                if (addend) v += St::ld4_last(a1p, 0);  // fused accumulation (the addend's only reader)
+                if (addend2) v += St::ld4_last(a2p, 0);
                 St::st4(dst, 0, v);
             } else {
 #pragma unroll

@@ -486,8 +486,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             const int64_t pix = ((int64_t)n * g.H + yy) * g.W + xx;
             typedef SnnStore<SBF> St;   // fp32 tensors, or bf16 (rounded here) in the bf16-storage mode
             if (ovec) {
-                if (addend) val += St::ld4(addend, pix * g.ld_add + nch);   // fused accumulation
-                if (addend2) val += St::ld4(addend2, pix * g.ld_add2 + nch);
+                if (addend) val += St::ld4_last(addend, pix * g.ld_add + nch);   // fused accumulation
+                if (addend2) val += St::ld4_last(addend2, pix * g.ld_add2 + nch);
                 St::st4(y, pix * g.ldy + nch, val);
             } else {
 #pragma unroll
@@ -780,8 +780,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_s2dgrad3(const float* __re
             const int64_t pix = ((int64_t)n * g.OH + hi) * g.OW + wi;
             typedef SnnStore<SBF> St;
             if (ovec) {
-                if (addend) val += St::ld4(addend, pix * g.ld_add + nch);
-                if (addend2) val += St::ld4(addend2, pix * g.ld_add2 + nch);
+                if (addend) val += St::ld4_last(addend, pix * g.ld_add + nch);
+                if (addend2) val += St::ld4_last(addend2, pix * g.ld_add2 + nch);
                 St::st4(y, pix * g.ldy + nch, val);
             } else {
 #pragma unroll

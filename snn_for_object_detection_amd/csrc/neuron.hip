@@ -24,6 +24,9 @@ extern "C" int snn_debug_set_bwd_abl(int v) { return (int)hipMemcpyToSymbol(HIP_
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef SNN_SCAN_NT_AUX
+#define SNN_SCAN_NT_AUX 2   // cache-policy operand of the reverse scan's last-use loads (gfx950: bit 1 = nt)
+#endif
 
 template <int VEC> struct Vec;
 template <> struct Vec<4> {
@@ -53,12 +56,27 @@ template <> struct Vec<1> {
 template <int VEC, bool SB> struct VecS;
 template <bool SB> struct VecS<4, SB> {
     static __device__ __forceinline__ f32x4 load(const float* base, int64_t i) { return SnnStore<SB>::ld4(base, i); }
+    // the same for a tensor nobody reads again soon (non-temporal: what stays in L2 / the memory-side cache should be the
+    // tensors that go from a producer straight to its consumer - conv -> scan -> conv, scan -> apply -> data gradient)
+    static __device__ __forceinline__ f32x4 load_last(const float* base, int64_t i) {
+        if constexpr (SNN_SCAN_NT_AUX == 0) return SnnStore<SB>::ld4(base, i);
+        else if constexpr (SB) return snn_unpack_bf16x4(__builtin_nontemporal_load(
+                                   reinterpret_cast<const snn_u32x2*>(reinterpret_cast<const unsigned short*>(base) + i)));
+        else return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + i));
+    }
     static __device__ __forceinline__ void store(float* base, int64_t i, f32x4 v) { SnnStore<SB>::st4(base, i, v); }
 };
 template <> struct VecS<8, true> {   // 8 bf16 values = 16 bytes
     static __device__ __forceinline__ f32x8 load(const float* base, int64_t i) {
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
         const u32x4_ r = *reinterpret_cast<const u32x4_*>(reinterpret_cast<const unsigned short*>(base) + i);
+        const f32x4 a = snn_unpack_bf16x4(snn_u32x2{r[0], r[1]}), b = snn_unpack_bf16x4(snn_u32x2{r[2], r[3]});
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ f32x8 load_last(const float* base, int64_t i) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_* src = reinterpret_cast<const u32x4_*>(reinterpret_cast<const unsigned short*>(base) + i);
+        const u32x4_ r = SNN_SCAN_NT_AUX == 0 ? *src : __builtin_nontemporal_load(src);
         const f32x4 a = snn_unpack_bf16x4(snn_u32x2{r[0], r[1]}), b = snn_unpack_bf16x4(snn_u32x2{r[2], r[3]});
         return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     }
@@ -71,6 +89,7 @@ template <> struct VecS<8, true> {   // 8 bf16 values = 16 bytes
 };
 template <bool SB> struct VecS<1, SB> {
     static __device__ __forceinline__ float load(const float* base, int64_t i) { return SnnStore<SB>::ld1(base, i); }
+    static __device__ __forceinline__ float load_last(const float* base, int64_t i) { return SnnStore<SB>::ld1(base, i); }
     static __device__ __forceinline__ void store(float* base, int64_t i, float v) { SnnStore<SB>::st1(base, i, v); }
 };
 template <int VEC> __device__ __forceinline__ float& lane(typename Vec<VEC>::type& v, int j);
@@ -380,12 +399,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
             const int tc = t < T ? t : T - 1;
             const int64_t row = (int64_t)tc * M + m;
             StepOps o;
-            o.x = VecS<VEC, SB>::load(y, row * ldy + c);
+            o.x = VecS<VEC, SB>::load_last(y, row * ldy + c);   // (the convolution's output: next read in the backward pass)
             if (PIPED || alpha) {
                 o.a = Vec<VEC>::load(alpha + (int64_t)tc * C + c);
                 o.b = Vec<VEC>::load(beta + (int64_t)tc * C + c);
             }
-            if (PIPED ? ADD : addend != nullptr) o.ad = VecS<VEC, SB>::load(addend, row * ld_add + c);
+            if (PIPED ? ADD : addend != nullptr) o.ad = VecS<VEC, SB>::load_last(addend, row * ld_add + c);   // (as y)
             return o;
         };
         StepOps sq[kPrefetch > 0 ? kPrefetch : 1];
@@ -460,8 +479,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
             }
             if (PIPED || !last_only) VecS<VEC, SB>::store(out, row * ldo + c, o);
             else if (t == T - 1) VecS<VEC, SB>::store(out, m * ldo + c, o);
-            if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE))
-                VecS<VEC, SB>::store(vdec, row * C + c, vd);
+            if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE)) {
+                // (non-temporal where the access is one plain 16-byte store: nobody reads v_dec before the backward pass,
+                // while `out` is the next convolution's operand and should be what stays in the caches)
+                if constexpr (VEC == 4 && !SB && SNN_SCAN_NT_AUX != 0) __builtin_nontemporal_store(vd, reinterpret_cast<f32x4*>(vdec + row * C + c));
+                else VecS<VEC, SB>::store(vdec, row * C + c, vd);
+            }
         }
         };
         if constexpr (VEC > 1 && SAVE != 2) {
@@ -680,6 +703,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
             if constexpr (SB && BUF) return __builtin_bit_cast(snn_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
             else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         };
+        auto bload_last = [&](const auto& rs, int off) -> R {   // the same for a tensor nobody reads again (aux 2 = nt)
+            if constexpr (SB && BUF) return __builtin_bit_cast(snn_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, SNN_SCAN_NT_AUX));
+            else return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, SNN_SCAN_NT_AUX));
+        };
         // eval-mode BatchNorm scale alpha[t][c] (apply_scale): fetched with the operand set - a load inside a branch of the
         // time loop makes the compiler's wait-count pass fall back to small vmcnt values for the whole step (it cannot
         // know whether the load was issued), which stalls on the prefetched set.  Zero records when unused.
@@ -693,12 +720,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 const __amdgpu_buffer_rsrc_t rg = slab_out(g_out, t, ldg);
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    go[q] = bload(rg, og[q]);
+                    go[q] = bload_last(rg, og[q]);
                 if (kNeedsState) {
                     const __amdgpu_buffer_rsrc_t rs = (NEURON == SNN_NEURON_LI_TANH) ? slab_out(state, t, C) : slab(state, t, C);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        st[q] = bload(rs, os[q]);
+                        st[q] = bload_last(rs, os[q]);
                 }
                 if (MODE != 0 || kNeedsX) {
                     const __amdgpu_buffer_rsrc_t ry = slab(y, t, ldy);
@@ -1270,8 +1297,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float* __restri
         const int64_t row = e / cv;
         const int c = (int)(e % cv) * VEC;
         const int64_t t = row / M;
-        V g = VecS<VEC, SB>::load(gx, row * C + c);
-        V yv = VecS<VEC, SB>::load(y, row * ldy + c);
+        V g = VecS<VEC, SB>::load_last(gx, row * C + c);      // last reads of both: dy is what the next kernels want cached
+        V yv = VecS<VEC, SB>::load_last(y, row * ldy + c);
         V a = Vec<VEC>::load(coefA + t * C + c);
         V b = Vec<VEC>::load(coefB + t * C + c);
         V k = Vec<VEC>::load(coefC + t * C + c);

@@ -109,6 +109,10 @@ template <> struct SnnStore<false> {
     static __device__ __forceinline__ f32x4 ld4(const void* base, int64_t i) {
         return *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + i);
     }
+    // the same for a tensor nobody reads again (non-temporal: a fused gradient addend is consumed by exactly this load)
+    static __device__ __forceinline__ f32x4 ld4_last(const void* base, int64_t i) {
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + i));
+    }
     static __device__ __forceinline__ float ld1(const void* base, int64_t i) { return static_cast<const float*>(base)[i]; }
     static __device__ __forceinline__ void st4(void* base, int64_t i, f32x4 v) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(base) + i) = v;
@@ -119,6 +123,9 @@ template <> struct SnnStore<true> {
     static constexpr int ES = 2;
     static __device__ __forceinline__ f32x4 ld4(const void* base, int64_t i) {
         return snn_unpack_bf16x4(*reinterpret_cast<const snn_u32x2*>(static_cast<const unsigned short*>(base) + i));
+    }
+    static __device__ __forceinline__ f32x4 ld4_last(const void* base, int64_t i) {
+        return snn_unpack_bf16x4(__builtin_nontemporal_load(reinterpret_cast<const snn_u32x2*>(static_cast<const unsigned short*>(base) + i)));
     }
     static __device__ __forceinline__ float ld1(const void* base, int64_t i) {
         return __builtin_bit_cast(float, (unsigned)static_cast<const unsigned short*>(base)[i] << 16);
