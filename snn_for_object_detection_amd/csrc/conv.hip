@@ -1950,8 +1950,10 @@ struct FirstGeom {
 // work), its PP pixel lanes walk the row; per pixel all nine input positions are loaded before any is tested.
 // SB (bf16-storage mode): the wide tensors - y (forward), dy / gx and the saved y (weight gradient) - are bf16; the event
 // frames x stay fp32.
+// (the weight gradient's grid is four blocks per CU - snn_conv2d_wgrad_splitk - so its instances are held to four waves per
+// SIMD: the BatchNorm-apply form needed 138 registers, three waves, and ran a quarter of its blocks in a second round)
 template <int CIN, int KS, bool WGRAD, bool BNAPPLY = false, bool SB = false>
-__global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(kThreads, WGRAD ? 4 : 1) void k_conv_first(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          FirstGeom g) {
     static_assert(CIN == 2, "float2 input pixels");
@@ -2013,6 +2015,15 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
             cc = *reinterpret_cast<const f32x4*>(cf + 2 * (int64_t)g.bn_tc);
         }
         float row_s[4] = {0.f, 0.f, 0.f, 0.f}, row_q[4] = {0.f, 0.f, 0.f, 0.f};
+        // weight gradient: the dy (gx, y) quads of a pixel are requested one pixel AHEAD of their use.  With the loads in
+        // front of the 72 fmaf that consume them a wave had two 16-byte accesses in flight and then none: 2.2 TB/s for a
+        // kernel that runs alone at the end of the backward pass (the step's tail).  The index of the pixel after the
+        // row's last is clamped (its quads are loaded and dropped): no branch around the loads.
+        [[maybe_unused]] f32x4 gv_next = {0.f, 0.f, 0.f, 0.f}, yv_next = gv_next;
+        if (WGRAD && pl < g.Wo) {
+            gv_next = St::ld4_last(dy, dyrow + pl * ldy);
+            if constexpr (BNAPPLY) yv_next = St::ld4_last(g.bn_y, byrow + pl * (int)g.bn_ldy);
+        }
         for (int ox = pl; ox < g.Wo; ox += PP) {
             float2 taps[KS][KS];
 #pragma unroll
@@ -2020,11 +2031,16 @@ __global__ __launch_bounds__(kThreads) void k_conv_first(const float* __restrict
 #pragma unroll
                 for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow[kh * LW + ox * g.stride + kw];
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (WGRAD) gv = St::ld4(dy, dyrow + ox * ldy);
-            if constexpr (WGRAD && BNAPPLY) {   // the statement of k_bn_bwd_apply (neuron.hip): same roundings
-                const f32x4 yv = St::ld4(g.bn_y, byrow + ox * (int)g.bn_ldy);
+            if (WGRAD) {
+                gv = gv_next;
+                const int oxn = ox + PP < g.Wo ? ox + PP : ox;
+                gv_next = St::ld4_last(dy, dyrow + oxn * ldy);
+                if constexpr (BNAPPLY) {   // the statement of k_bn_bwd_apply (neuron.hip): same roundings
+                    const f32x4 yv = yv_next;
+                    yv_next = St::ld4_last(g.bn_y, byrow + oxn * (int)g.bn_ldy);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) gv[c] = ca[c] * gv[c] + cb[c] * yv[c] + cc[c];
+                    for (int c = 0; c < 4; ++c) gv[c] = ca[c] * gv[c] + cb[c] * yv[c] + cc[c];
+                }
             }
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
