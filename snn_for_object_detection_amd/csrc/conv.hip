@@ -1944,6 +1944,7 @@ struct FirstGeom {
     const float* bn_coef;
     int bn_tc;   // T * C: distance between the three coefficient planes
     int bn_fps;  // frames per timestep
+    int rs;      // output rows a block stages (input rows -> LDS) and computes between two barriers: first_layer_rs()
 };
 
 // One block walks output ROWS (block-uniform row index: the image / row split and the vertical bounds are scalar
@@ -1980,30 +1981,45 @@ __global__ __launch_bounds__(kThreads, WGRAD ? 4 : 1) void k_conv_first(const fl
 #pragma unroll
         for (int c = 0; c < 8; ++c) sred[threadIdx.x][c] = 0.0;
     }
-    for (int r = grp * g.group_rows + grp_j; r < r_end; r += g.group_blocks) {
-        const int img = r / g.Ho, oy = r - img * g.Ho;
-        const int iy0 = oy * g.stride - g.pad;
-        const float* xrow[KS];
-        bool rowok[KS];
-#pragma unroll
-        for (int kh = 0; kh < KS; ++kh) {
-            const int iy = iy0 + kh;
-            rowok[kh] = (unsigned)iy < (unsigned)g.H;
-            xrow[kh] = x + ((int64_t)img * g.H + (rowok[kh] ? iy : 0)) * g.W * g.ldx;
-        }
-        // the KS input rows (with their zero padding) go through LDS: the 16 lanes of a pixel read the same nine
-        // positions, and same-address lanes of a global load are separate accesses for the texture addresser
-        const int LW = g.W + 2 * g.pad;
+    // The KS input rows of an output row (with their zero padding) go through LDS: the 16 lanes of a pixel read the same nine
+    // positions, and same-address lanes of a global load are separate accesses for the texture addresser.  A block stages
+    // the input rows of g.rs of its output rows at once - ONE pair of barriers and ONE exposed memory latency per g.rs rows,
+    // and the staging loads of a thread are all requested before the first is written to LDS (four at a time, addresses
+    // clamped instead of branched around: the loop used to wait for every single load, six dependent round trips per row).
+    const int LW = g.W + 2 * g.pad;
+    const int stage_elems = KS * LW;                   // float2 elements of one output row's input rows
+    for (int r0 = grp * g.group_rows + grp_j; r0 < r_end; r0 += g.group_blocks * g.rs) {
+        int nrows = (r_end - r0 + g.group_blocks - 1) / g.group_blocks;   // block-uniform
+        nrows = nrows < g.rs ? nrows : g.rs;
+        const int total = nrows * stage_elems;
         __syncthreads();
+        for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kThreads) {
+            float2 t[4];
 #pragma unroll
-        for (int kh = 0; kh < KS; ++kh)
-            for (int ixp = threadIdx.x; ixp < LW; ixp += kThreads) {
-                const int ix = ixp - g.pad;
-                const bool ok = rowok[kh] && (unsigned)ix < (unsigned)g.W;
-                const float2 t = *reinterpret_cast<const float2*>(xrow[kh] + (ok ? ix * ldx : 0));
-                srow[kh * LW + ixp] = ok ? t : make_float2(0.f, 0.f);
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * kThreads;
+                const int ec = e < total ? e : total - 1;
+                const int jk = ec / LW, ixp = ec - jk * LW;       // (row of the stage) * KS + kh, padded column
+                const int j = jk / KS, kh = jk - j * KS;
+                const int r = r0 + j * g.group_blocks;
+                const int img = r / g.Ho, oy = r - img * g.Ho;
+                const int iy = oy * g.stride - g.pad + kh, ix = ixp - g.pad;
+                const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const float2 v = *reinterpret_cast<const float2*>(
+                    x + ((int64_t)img * g.H + (ok ? iy : 0)) * g.W * g.ldx + (ok ? ix * ldx : 0));
+                t[u] = ok ? v : make_float2(0.f, 0.f);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * kThreads;
+                if (e < total) srow[e] = t[u];
+            }
+        }
         __syncthreads();
+      for (int jrow = 0; jrow < nrows; ++jrow) {
+        const int r = r0 + jrow * g.group_blocks;
+        const int img = r / g.Ho;
+        const float2* srow_r = srow + jrow * stage_elems;
         const int64_t dyrow = (int64_t)r * g.Wo * g.ldy + cg * 4;   // element index of the row's first pixel in dy / out
         int64_t byrow = 0;
         f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = ca, cc = ca;
@@ -2029,7 +2045,7 @@ __global__ __launch_bounds__(kThreads, WGRAD ? 4 : 1) void k_conv_first(const fl
 #pragma unroll
             for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow[kh * LW + ox * g.stride + kw];
+                for (int kw = 0; kw < KS; ++kw) taps[kh][kw] = srow_r[kh * LW + ox * g.stride + kw];
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
             if (WGRAD) {
                 gv = gv_next;
@@ -2077,6 +2093,7 @@ __global__ __launch_bounds__(kThreads, WGRAD ? 4 : 1) void k_conv_first(const fl
                 sred[threadIdx.x][4 + c] += (double)row_q[c];
             }
         }
+      }
     }
     if (!WGRAD && stats) {
         // block sum over the PP pixel lanes of every channel, in lane order
@@ -2120,6 +2137,15 @@ static bool first_layer_shape(int Cin, int Cout, int KH, int KW) {
     const int cgs = Cout / 4;
     return (cgs & (cgs - 1)) == 0;
 }
+
+// output rows a block stages at once: as many as fit 20 KiB of LDS - next to the 19 KiB of reduction scratch both forms
+// carry, four blocks per CU stay resident (with 29 KiB the weight gradient fell to three and lost a fifth) - at most 4
+static int first_layer_rs(int W, int pad) {
+    const int per_row = 3 * (W + 2 * pad) * (int)sizeof(float2);
+    int rs = (20 << 10) / per_row;
+    return rs < 1 ? 1 : (rs > 4 ? 4 : rs);
+}
+static size_t first_layer_lds(int W, int pad) { return (size_t)first_layer_rs(W, pad) * 3 * (W + 2 * pad) * sizeof(float2); }
 
 static int first_layer_blocks(int64_t rows) {  // grid of the row-walking kernels = slabs of the weight gradient
     int64_t b = rows < 4 * snn_num_cu() ? rows : 4 * snn_num_cu();
@@ -2248,7 +2274,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
         (int64_t)W * ldx < 0x7fffffffLL && (int64_t)Wo * ldy < 0x7fffffffLL && W + 2 * pad <= 1408 &&
         (Wo - 1) * stride + 3 <= W + 2 * pad) {
         FirstGeom fg = {ldx, ldy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), 0, nullptr,
-                        nullptr, 0, nullptr, 0, 1};
+                        nullptr, 0, nullptr, 0, 1, first_layer_rs(W, pad)};
         int blocks = fg.rows < 8 * snn_num_cu() ? fg.rows : 8 * snn_num_cu();
         fg.group_blocks = blocks;
         if (bn_partial) {
@@ -2262,10 +2288,10 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
         }
         if (sbf)
             hipLaunchKernelGGL((k_conv_first<2, 3, false, false, true>), dim3((unsigned)blocks), dim3(kThreads),
-                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
+                               first_layer_lds(W, pad), (hipStream_t)stream, x, w, nullptr, y, fg);
         else
             hipLaunchKernelGGL((k_conv_first<2, 3, false>), dim3((unsigned)blocks), dim3(kThreads),
-                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, w, nullptr, y, fg);
+                               first_layer_lds(W, pad), (hipStream_t)stream, x, w, nullptr, y, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_fwd");
         return 0;
     }
@@ -2491,9 +2517,9 @@ extern "C" int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx,
                     aligned16(y) && aligned16(coef) && (int64_t)Wo * ldy < 0x7fffffffLL && (int64_t)Wo * ldgx < 0x7fffffffLL,
                 "snn_conv2d_wgrad_bn: shape / alignment not covered (ask snn_conv2d_wgrad_bn_supported)");
     FirstGeom fg = {ldx, ldgx, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
-                    y, ldy, coef, T * Cout, frames_per_step};
+                    y, ldy, coef, T * Cout, frames_per_step, first_layer_rs(W, pad)};
     hipLaunchKernelGGL((k_conv_first<2, 3, true, true>), dim3((unsigned)splitk), dim3(kThreads),
-                       (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, gx, workspace, fg);
+                       first_layer_lds(W, pad), (hipStream_t)stream, x, nullptr, gx, workspace, fg);
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad_bn");
     return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * KH * KW * Cin, splitk, accumulate, (hipStream_t)stream);
 }
@@ -2519,13 +2545,13 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.Ktot = KH * KW * Cin;
     if (first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, sbf)) {
         FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
-                        nullptr, 0, nullptr, 0, 1};
+                        nullptr, 0, nullptr, 0, 1, first_layer_rs(W, pad)};
         if (sbf)
             hipLaunchKernelGGL((k_conv_first<2, 3, true, false, true>), dim3((unsigned)splitk), dim3(kThreads),
-                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
+                               first_layer_lds(W, pad), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         else
             hipLaunchKernelGGL((k_conv_first<2, 3, true>), dim3((unsigned)splitk), dim3(kThreads),
-                               (size_t)3 * (W + 2 * pad) * sizeof(float2), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
+                               first_layer_lds(W, pad), (hipStream_t)stream, x, nullptr, dy, workspace, fg);
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
         return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
     }
