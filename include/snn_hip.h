@@ -118,7 +118,8 @@ int snn_nhwc_to_nchw(const float* src, float* dst, int64_t N, int C, int H, int 
 /* weights [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] (operand of the data-gradient conv) */
 int snn_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
 /* the same for every conv weight of a flat parameter buffer in ONE launch: table[l] = {element offset, Cout, KH*KW, Cin}
- * (device memory, int64); flat_wt mirrors the offsets of flat_w */
+ * (device memory, int64); flat_wt mirrors the offsets of flat_w.  A layer is indexed in 32 bits: Cout*KH*KW*Cin < 2^31
+ * (the table is device memory: the caller that builds it checks). */
 int snn_weight_transpose_batched(const float* flat_w, float* flat_wt, const int64_t* table, int n_layers, void* stream);
 /* Pre-split weight image for the convolution kernels: every group of 4 consecutive floats of `w` (n floats, n % 4 == 0,
  * both buffers 16-byte aligned, `out` as large as `w`) becomes 4 high + 4 low 16-bit pieces - fp16 pieces of w * 2^8 for

@@ -79,18 +79,35 @@ __global__ void k_weight_transpose(const float* __restrict__ w, float* __restric
 // walks layer l with stride gridDim.x.  (47 per-layer launches of 6.5 us each sat in the backward critical path.)
 __global__ void k_weight_transpose_batched(const float* __restrict__ flat_w, float* __restrict__ flat_wt,
                                            const int64_t* __restrict__ table) {
+    // Per tap a Cout x Cin matrix is transposed in 32 x 32 tiles through LDS: rows of 32 consecutive ci are read (128
+    // contiguous bytes), rows of 32 consecutive co are written.  (The first form gathered one element per lane with a
+    // stride of taps * Cin floats - every lane its own cache line: 43 us between the optimiser and the first forward kernel
+    // of every step.)  32-bit index arithmetic: a layer's weights are far below 2^31 elements (the caller that builds the
+    // device-side table checks it).
+    __shared__ float tile[32][33];
     const int64_t* d = table + (int64_t)blockIdx.y * 4;
     const int64_t off = d[0];
-    const int Cout = (int)d[1], taps = (int)d[2], Cin = (int)d[3];
+    const unsigned Cout = (unsigned)d[1], taps = (unsigned)d[2], Cin = (unsigned)d[3];
     const float* w = flat_w + off;
     float* wt = flat_wt + off;
-    const int64_t total = (int64_t)Cout * taps * Cin;
-    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
-        int co = (int)(e % Cout);
-        int64_t r = e / Cout;
-        int tap = (int)(r % taps);
-        int ci = (int)(r / taps);
-        wt[e] = w[((int64_t)co * taps + tap) * Cin + ci];
+    const unsigned tco = (Cout + 31) / 32, tci = (Cin + 31) / 32;
+    const unsigned ntiles = taps * tco * tci;
+    const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const unsigned tap = t / (tco * tci), rem = t - tap * (tco * tci);
+        const unsigned co0 = (rem / tci) * 32, ci0 = (rem % tci) * 32;
+#pragma unroll
+        for (unsigned k = 0; k < 32; k += 8) {
+            const unsigned co = co0 + ty + k, ci = ci0 + tx;
+            if (co < Cout && ci < Cin) tile[ty + k][tx] = w[(co * taps + tap) * Cin + ci];
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned k = 0; k < 32; k += 8) {
+            const unsigned ci = ci0 + ty + k, co = co0 + tx;
+            if (ci < Cin && co < Cout) wt[(ci * taps + tap) * Cout + co] = tile[tx][ty + k];
+        }
+        __syncthreads();
     }
 }
 

@@ -111,6 +111,9 @@ class FlatTrainer:
                 p._snn_grad_slot = slot
             if p.dim() == 4 and self.flat_wt is not None:
                 o, i, kh, kw = p.shape
+                if p.numel() >= 2 ** 31:
+                    raise RuntimeError("FlatTrainer: a convolution weight with 2^31 or more elements (the batched transpose "
+                                       "indexes a layer in 32 bits)")
                 table.append([off, o, kh * kw, i])
                 p._snn_wt = self.flat_wt[off:off + p.numel()].view(i, kh, kw, o)
                 p._snn_wt_version = -1  # not valid yet
