@@ -15,6 +15,7 @@ Here, per process (= per GPU):
 ``torch.distributed`` is the transport only (backend ``nccl`` = RCCL on ROCm, ``gloo`` in CPU tests).
 """
 
+import weakref
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -155,6 +156,7 @@ class FlatTrainer:
         self.broadcast_buffers = broadcast_buffers
         # gradient exchange overlapped with the backward pass: see ``overlap_from``
         self._early_lo: Optional[int] = None
+        self._early_first: Optional[int] = None
         self._early_work = None
         self._comm_stream = None
         self._flags_work = None
@@ -163,14 +165,43 @@ class FlatTrainer:
         if dev.type == "cuda" and _HF.USE_WGRAD_STREAM:
             # the weight-gradient stream is chosen NOW, with the device idle (its choice probes hardware-queue sharing)
             _HF._side_stream(dev)
+        # an earlier trainer's hook must not outlive it on the model (a rebuilt trainer - checkpoint resume, another
+        # ``overlap_grad_exchange`` setting, one rank - would inherit a stray all-reduce of the OLD trainer's buffers)
+        if hasattr(model, "_snn_neck_grads_ready"):
+            model._snn_neck_grads_ready = None
+        self._grad_group = process_group   # the group the GRADIENT exchange runs on (see below)
+        self.overlap_disabled_reason: Optional[str] = None
         if (overlap_grad_exchange and self.exchange and hasattr(model, "_snn_neck_grads_ready")
                 and all(hasattr(model, a) for a in ("neck_net", "head_net"))):
-            # a SODa detector: neck + head gradients go out while the backbone's backward pass still runs
-            self.overlap_from([model.neck_net, model.head_net])
-            model._snn_neck_grads_ready = self.early_all_reduce
-            if dev.type == "cuda":
-                self._comm_stream = _HF.concurrent_stream(torch.cuda.current_stream(dev),
-                                                          avoid=tuple(_HF._SIDE_STREAMS.values()))
+            # a SODa detector: neck + head gradients go out while the backbone's backward pass still runs.  The hook
+            # fires when the backward pass crosses the backbone / neck boundary; at that point only gradients written
+            # through GradSlots are in ``flat_grad`` - a gradient that travels through autograd's ``p.grad`` is folded
+            # in by ``step()``, AFTER the early exchange - so the overlap needs a slot on every early parameter.
+            lo = self.overlap_from([model.neck_net, model.head_net])
+            if not all(hasattr(p, "_snn_grad_slot") for p in self._early_params()):
+                self._early_lo = None
+                self.overlap_disabled_reason = ("parameters of the neck / head without a gradient slot "
+                                                "(use_grad_slots=False): one all-reduce in step()")
+            else:
+                ref = weakref.ref(self)
+
+                def _hook():
+                    tr = ref()
+                    if tr is not None:
+                        tr.early_all_reduce()
+
+                model._snn_neck_grads_ready = _hook
+                if dev.type == "cuda":
+                    self._comm_stream = _HF.concurrent_stream(torch.cuda.current_stream(dev),
+                                                              avoid=tuple(_HF._SIDE_STREAMS.values()))
+                    # ProcessGroupNCCL runs the collectives of ONE group on one internal stream: on the group that also
+                    # carries the SyncBatchNorm exchanges, the backbone's first SyncBN backward all-reduce would queue
+                    # behind the multi-MB tail exchange and the main stream would block on it.  The gradient exchange
+                    # therefore gets a communicator of its own (every rank builds its trainer: a collective call).
+                    if dist.get_backend(process_group) == "nccl":
+                        self._grad_group = dist.new_group(ranks=dist.get_process_group_ranks(process_group)
+                                                          if process_group is not None else None, backend="nccl")
+                assert lo == self._early_lo
         self.refresh_transposed_weights()
 
     # ------------------------------------------------------------------ overlapped gradient exchange
@@ -189,13 +220,30 @@ class FlatTrainer:
         if first is None or any(id(p) not in ids for p in self.params[first:]) or len(ids) != len(self.params) - first:
             raise RuntimeError("overlap_from: the modules' parameters are not the tail of the trainer's parameter order")
         self._early_lo = self._offsets[first]
+        self._early_first = first
         return self._early_lo
+
+    def _early_params(self) -> List[torch.nn.Parameter]:
+        return self.params[self._early_first:] if self._early_lo is not None else []
 
     def early_all_reduce(self) -> None:
         """Start the all-reduce of ``flat_grad[early_lo:]`` on a communication stream behind everything the main and
-        the weight-gradient streams hold at this point.  No-op for a single rank or without ``overlap_from``."""
-        if not self.exchange or self._early_lo is None or self._early_work is not None:
+        the weight-gradient streams hold at this point.  No-op for a single rank or without ``overlap_from``.
+
+        ONE backward pass per ``step()``: a second pass (micro-batch accumulation, several losses) would add local
+        gradients onto a tail that is already summed over the ranks - possibly while the collective still runs - so the
+        second call raises instead of returning silently wrong gradients."""
+        if not self.exchange or self._early_lo is None:
             return
+        if self._early_work is not None:
+            raise RuntimeError("FlatTrainer: a second backward pass reached the backbone / neck boundary before step(): "
+                               "the neck / head gradients of the first pass are already being summed over the ranks. "
+                               "Accumulate micro-batches with FlatTrainer(..., overlap_grad_exchange=False)")
+        for p in self._early_params():
+            if p.grad is not None:
+                raise RuntimeError("FlatTrainer: a neck / head parameter received its gradient through autograd's .grad "
+                                   "instead of its gradient slot; the overlapped exchange would miss it. Build the "
+                                   "trainer with overlap_grad_exchange=False")
         part = self.flat_grad[self._early_lo:]
         if part.is_cuda:
             if self._comm_stream is None:   # (normally taken in __init__, where probing it costs no pipeline drain)
@@ -206,9 +254,16 @@ class FlatTrainer:
             for st in _HF._SIDE_STREAMS.values():
                 comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self._grad_group, async_op=True)
         else:
-            self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self._grad_group, async_op=True)
+
+    def _join_early(self) -> None:
+        """Current stream waits for the early exchange (the handle stays: ``step()`` still has the head to reduce)."""
+        if self._early_work is not None:
+            self._early_work.wait()
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def refresh_transposed_weights(self) -> None:
         """Re-derive every ``p._snn_wt`` from the current weights (one launch).  ``_Conv2d.backward`` uses a cached
@@ -272,7 +327,7 @@ class FlatTrainer:
         if self.flat_grad.is_cuda:
             wgrad_stream_sync()  # nothing may still be writing into the buffer that is about to be cleared
         if self._early_work is not None:   # a backward pass whose step() never came: let its collective finish first
-            self._early_work.wait()
+            self._join_early()
             self._early_work = None
         _HF.reset_backward_state()
         self.flat_grad.zero_()
@@ -282,8 +337,13 @@ class FlatTrainer:
 
     def _collect_autograd_grads(self) -> None:
         """Parameters whose gradient came through autograd (ops without slot support) are folded in."""
-        for p, slot, gview in zip(self.params, self.slots, self.grad_views):
+        early = self._early_first if (self._early_work is not None and self._early_lo is not None) else len(self.params)
+        for k, (p, slot, gview) in enumerate(zip(self.params, self.slots, self.grad_views)):
             if p.grad is not None:
+                if k >= early:
+                    raise RuntimeError("FlatTrainer.step: a neck / head parameter holds an autograd .grad while its slice "
+                                       "of the flat gradient is being all-reduced (it would be added after - or during - "
+                                       "the exchange); build the trainer with overlap_grad_exchange=False")
                 if slot.written:
                     gview.add_(p.grad)
                 else:
@@ -299,13 +359,11 @@ class FlatTrainer:
             return
         if self._early_work is not None:
             if self._early_lo > 0:
-                dist.all_reduce(self.flat_grad[: self._early_lo], op=dist.ReduceOp.SUM, group=self.group)
-            self._early_work.wait()            # the current stream waits for the collective
-            if self._comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                dist.all_reduce(self.flat_grad[: self._early_lo], op=dist.ReduceOp.SUM, group=self._grad_group)
+            self._join_early()                 # the current stream waits for the collective
             self._early_work = None
         else:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self._grad_group)
 
     def _written_flags(self) -> List[bool]:
         """Which parameters received a gradient this step.  ``torch.optim.Adamax`` skips parameters whose ``.grad`` is
@@ -458,9 +516,13 @@ class FlatTrainer:
 
     # ------------------------------------------------------------------ helpers for tests / checkpoints
     def synchronize(self) -> None:
-        """Join the weight-gradient side stream: after this the current stream may read ``flat_grad``."""
+        """Join the weight-gradient side stream AND an early gradient exchange still in flight: after this the current
+        stream may read (or clip, in place) ``flat_grad``.  With the overlapped exchange (N > 1, SODa) the neck / head
+        part ``flat_grad[early_lo:]`` is then already SUMMED over the ranks while the backbone part is still local until
+        ``step()``; ``FlatTrainer(overlap_grad_exchange=False)`` keeps everything local until ``step()``."""
         if self.flat_grad.is_cuda:
             wgrad_stream_sync()
+        self._join_early()
 
     def averaged_grad(self) -> torch.Tensor:
         """The (all-reduced) flat gradient divided by world_size, as the optimiser sees it."""

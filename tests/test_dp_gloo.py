@@ -120,7 +120,10 @@ def _overlap_worker(rank, world, port, out_dir):
         tr.flat_grad.copy_(local)
         tr.early_all_reduce()                     # what the backward hook does at the boundary
         assert tr._early_work is not None
-        tr.early_all_reduce()                     # a second hook call in the same pass is a no-op
+        with pytest.raises(RuntimeError, match="second backward pass"):
+            tr.early_all_reduce()                 # a second backward pass before step() would corrupt the summed tail
+        tr.synchronize()                          # joins the early exchange: the tail may be read now (already summed)
+        assert tr._early_work is not None         # ... and step() still knows the tail went out
         tr.all_reduce()                           # step(): the rest + join
         assert tr._early_work is None
         whole = local.clone()
@@ -137,6 +140,60 @@ def test_split_gradient_exchange_equals_one_allreduce(tmp_path):
     for r in range(world):
         d = torch.load(tmp_path / f"ov{r}.pt")
         assert torch.equal(d["split"], d["whole"])
+
+
+def _soda_noslot_worker(rank, world, port, out_dir):
+    """a SODa model whose gradients arrive through autograd's ``.grad`` (``use_grad_slots=False``) must NOT
+    take the overlapped exchange - the hook would reduce a tail that holds nothing yet - and still sum every gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import snn_for_object_detection_amd as S
+        from snn_for_object_detection_amd.trainer import FlatTrainer, _storage_view
+        torch.manual_seed(1)
+        model = S.TinyYolo(num_classes=2, time_window=0)
+        out = {}
+        for slots in (False, True):
+            tr = FlatTrainer(model, lr=1e-3, use_grad_slots=slots)
+            assert (model._snn_neck_grads_ready is not None) == slots
+            assert (tr.overlap_disabled_reason is None) == slots
+            tr.zero_grad()
+            g = torch.Generator().manual_seed(7 + rank)
+            local = torch.randn(tr.flat_grad.shape, generator=g)
+            if slots:
+                tr.flat_grad.copy_(local)             # what the backward kernels do through the slots
+                model._snn_neck_grads_ready()         # the backward pass crosses the backbone / neck boundary
+                assert tr._early_work is not None
+                tr.params[-1].grad = torch.zeros_like(tr.params[-1])   # a late autograd gradient for the tail ...
+                with pytest.raises(RuntimeError, match="overlap_grad_exchange=False"):
+                    tr._collect_autograd_grads()                      # ... is refused, not added after the exchange
+                tr.params[-1].grad = None
+            else:
+                for k, p in enumerate(tr.params):      # the same values, arriving as autograd's .grad
+                    p.grad = _storage_view(local, tr._offsets[k], p.data).clone()
+                assert model._snn_neck_grads_ready is None
+                tr._collect_autograd_grads()
+            tr.all_reduce()
+            whole = local.clone()
+            dist.all_reduce(whole)
+            out[slots] = (tr.flat_grad[: tr.numel].clone(), whole[: tr.numel])
+        # a new trainer WITHOUT overlap on the same model must not inherit the old trainer's hook
+        FlatTrainer(model, lr=1e-3, overlap_grad_exchange=False)
+        assert model._snn_neck_grads_ready is None
+        torch.save(out, os.path.join(out_dir, f"ns{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_soda_without_grad_slots_falls_back_to_one_allreduce(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_soda_noslot_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(tmp_path / f"ns{r}.pt")
+        for slots in (False, True):
+            got, want = d[slots]
+            assert torch.equal(got, want)
 
 
 @pytest.mark.timeout(300)

@@ -36,7 +36,7 @@ def _shard(rank):
     return (synthetic_events(T, B_RANK, H, W, p=0.08, seed=10 + rank), synthetic_labels(B_RANK, seed=20 + rank))
 
 
-def _worker(rank, world, port, out_dir, sync_bn):
+def _worker(rank, world, port, out_dir, sync_bn, grad_slots=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
@@ -44,7 +44,8 @@ def _worker(rank, world, port, out_dir, sync_bn):
         from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters, convert_sync_batchnorm
         torch.manual_seed(100 + rank)            # ranks start from different weights; the broadcast aligns them
         model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
-        tr = FlatTrainer(model, lr=1e-3)
+        tr = FlatTrainer(model, lr=1e-3, use_grad_slots=grad_slots)
+        assert (tr._early_lo is not None) == grad_slots   # no overlapped exchange without slots on the neck / head
         broadcast_parameters(tr)
         if sync_bn:
             convert_sync_batchnorm(model)
@@ -53,7 +54,11 @@ def _worker(rank, world, port, out_dir, sync_bn):
         tr.zero_grad()
         loss = model.training_step((X.cuda(), labels.cuda()))
         loss.backward()
+        # between backward() and step(): synchronize() joins the weight-gradient stream AND the early exchange, so the
+        # neck / head part is already summed over the ranks while the backbone part is still this rank's own
         tr.synchronize()
+        if not grad_slots:
+            tr._collect_autograd_grads()
         local = {n: g.detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
         tr.step()
         tr.sync_buffers()                        # rank 0's BatchNorm buffers everywhere (DDP's broadcast_buffers)
@@ -61,21 +66,22 @@ def _worker(rank, world, port, out_dir, sync_bn):
         avg = {n: (g / world).detach().cpu().clone() for n, g in tr.grads_by_name(model).items()}
         torch.save({"start": start, "loss": loss.item(), "local": local, "avg": avg,
                     "after": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
-                    "backend": dist.get_backend(), "world": dist.get_world_size()},
+                    "backend": dist.get_backend(), "world": dist.get_world_size(), "overlapped": tr._early_lo is not None},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("sync_bn", [False, True], ids=["rank-local-bn", "sync-bn"])
-def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, sync_bn):
+@pytest.mark.parametrize("sync_bn,grad_slots", [(False, True), (True, True), (False, False)],
+                         ids=["rank-local-bn", "sync-bn", "autograd-grads-no-overlap"])
+def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, sync_bn, grad_slots):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     import snn_for_object_detection_amd as S
     from oracle.net import SODaRef
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), sync_bn), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), sync_bn, grad_slots), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
     assert r[0]["world"] == 2
     for k in r[0]["start"]:                                   # broadcast from rank 0
@@ -118,6 +124,15 @@ def test_two_rank_training_step_matches_cpu_ddp_restatement(tmp_path, hip_lib, s
             assert torch.equal(r[0]["avg"][n], r[1]["avg"][n]), n            # one all-reduce: identical on both ranks
             worst = max(worst, rel_err(r[0]["avg"][n], g))
     assert worst < 1e-3, worst
+    # what a caller reads between backward() and step() (gradient-norm logging, clipping): the part that went out from
+    # the backward hook is the rank SUM already, the rest is rank-local and sums to the exchanged gradient
+    for n in want:
+        early = r[0]["overlapped"] and n.split(".")[0] in ("neck_net", "head_net")
+        for k in range(world):
+            if early:
+                assert torch.equal(r[k]["local"][n] / world, r[k]["avg"][n]), n
+        if not early:
+            assert torch.equal((r[0]["local"][n] + r[1]["local"][n]) / world, r[0]["avg"][n]), n
     # the optimiser step: torch.optim.Adamax on the oracle's averaged gradient, from the same start
     params = {n: torch.nn.Parameter(r[0]["start"][n].clone()) for n in want}
     for n, p in params.items():
