@@ -71,6 +71,50 @@ def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     return PEAK_F32_MATRIX_TFLOPS, "fp32 MFMA"
 
 
+def roofline_head(name, row, fwd_prec, bwd_prec, sb):
+    """Which roof binds a kernel family is decided by its ARITHMETIC INTENSITY (algorithmic FLOPs / algorithmic bytes of
+    its launches) against the ridge of its own peak pair - matrix peak of its arithmetic / 8 TB/s - not by its
+    name: a convolution family whose intensity lies below the ridge (the weight gradients of a step average 70 FLOP/B
+    against a ridge of 104) is HBM-bound.  Both fractions stay in the line (``frac_mfma`` / ``frac_hbm``)."""
+    hbm_basis = (f"HBM3E 8 TB/s spec (6.3 TB/s measured copy rate); algorithmic bytes = {2 if sb else 4} B per "
+                 "tensor element the kernel must touch")
+    if not name.startswith("k_conv") or row["bytes"] <= 0:
+        # the fused norm + neuron scans and the other pointwise kernels move bytes: priced against HBM
+        return {"bound": "hbm", "kernel": name, "achieved": row["gbs"], "peak": PEAK_HBM_GBS, "peak_basis": hbm_basis,
+                "unit": "GB/s", "frac": row["gbs"] / PEAK_HBM_GBS}
+    peak, peak_note = mfma_peak_for(name, fwd_prec, bwd_prec)
+    intensity = row["flops"] / row["bytes"]
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    common = {"kernel": name, "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+              "frac_mfma": row["tflops"] / peak, "mfma_peak": peak, "mfma_peak_basis": peak_note}
+    if intensity < ridge:
+        return {"bound": "hbm", **common, "achieved": row["gbs"], "peak": PEAK_HBM_GBS,
+                "peak_basis": hbm_basis + f"; the family's intensity {intensity:.0f} FLOP/B is below the ridge "
+                                          f"{ridge:.0f} of {peak_note}",
+                "unit": "GB/s", "frac": row["gbs"] / PEAK_HBM_GBS}
+    return {"bound": "mfma", **common, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
+            "unit": "TFLOP/s", "frac": row["tflops"] / peak}
+
+
+def chain_row(table, neuron_steps, profiled_steps, sb):
+    """The Norm + neuron CHAIN as one row: forward scan + reverse scan + BatchNorm-backward apply time against SURVEY
+    8(d)'s ideal-fusion bytes - 5 tensors per neuron-timestep (fwd: read y, write z; bwd: read dz, read y, write dy) =
+    20 B with fp32 tensors, 10 B with bf16 - NOT the bytes each of today's kernels moves (the per-kernel rows)."""
+    keys = [k for k in table if k.startswith(("k_affine_neuron_fwd", "k_affine_neuron_bwd", "k_bn_bwd_apply", "k_lif_bwd"))]
+    ms = sum(table[k]["ms"] for k in keys)
+    moved = sum(table[k]["bytes"] for k in keys)
+    if ms <= 0 or neuron_steps <= 0:
+        return None
+    per = 10.0 if sb else 20.0
+    ideal = per * neuron_steps
+    gbs = ideal / (ms * 1e-3) / 1e9
+    return {"kernel": "chain: Norm + neuron (fwd scan + bwd scan + BN-backward apply)", "members": sorted(keys),
+            "ms_per_step": ms / profiled_steps, "neuron_timesteps_per_step": neuron_steps / profiled_steps,
+            "ideal_bytes_per_neuron_timestep": per, "moved_bytes_per_neuron_timestep": moved / neuron_steps,
+            "traffic_ratio": moved / ideal, "gbs": gbs, "frac_hbm": gbs / PEAK_HBM_GBS,
+            "basis": "SURVEY 8(d): fused Norm+LIF kernel alone = 5 x s bytes per neuron-timestep"}
+
+
 def synthetic_batch(T, B, H, W, num_classes, device, seed, p=0.05):
     g = torch.Generator().manual_seed(seed)
     X = (torch.rand(T, B, 2, H, W, generator=g) < p).float()
@@ -146,6 +190,24 @@ def dominant_template(prof):
             "launches_per_step": calls // 2}
 
 
+def host_cpu():
+    """CPU model and core counts of this host (printed beside the baseline)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"cpu_model": model, "host_logical_cores": os.cpu_count(), "cores_available_to_process": usable}
+
+
 def cpu_baseline(config, H, W, num_classes, threads, p):
     """Time the oracle (port of the reference path) on the host cores: 1 warm-up + 2 timed steps."""
     from oracle.net import BlockRef, SODaRef
@@ -183,6 +245,7 @@ def cpu_baseline(config, H, W, num_classes, threads, p):
         "value": sample_T * sample_B / best,
         "unit": "event-frames/s",
         "cores": threads,
+        **host_cpu(),
         "kind": "port",
         "sample": f"oracle (pure-PyTorch fp32 restatement, time-outer loop; norse not installed) fwd+bwd on "
                   f"{CONFIGS[config]['label']} B={sample_B} T={sample_T}, best of 2 after 1 warm-up, {best:.2f} s/step",
@@ -226,11 +289,40 @@ def emit_json(obj) -> None:
         os.write(_JSON_FD, line)
 
 
-def dry_run(args, world: int, rank: int) -> None:
-    """The multi-process control flow without a GPU: rendezvous, one all-reduce, the rank-0 JSON line."""
+def build_model(args, cfg, classes, device):
+    """-> (model, lr): the workload's network with the reference initialisation (same seed on every rank)."""
+    import snn_for_object_detection_amd as S
+    torch.manual_seed(2)
+    if args.config == "deep12":
+        model = S.BlockGen(2, deep12_cfg())
+        for m in model.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        return model.to(device).train(), 1e-3
+    model = S.TinyYolo(num_classes=classes, time_window=0).to(device).train()
+    return model, model.hparams.learning_rate
+
+
+def replicas_equal(trainer, dist, what="flat_param") -> bool:
+    """Every rank holds the same buffer (ranks see different shards: a missing or partial exchange shows here)."""
+    chk = getattr(trainer, what).double().abs().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool((lo == hi).item())
+
+
+def dry_run(args, world: int, rank: int) -> int:
+    """The multi-process control flow of the N > 1 step without a GPU: rendezvous, the REAL model and ``FlatTrainer`` of the
+    workload on the CPU, and per step every collective the real step issues, in the order it issues them - weight
+    broadcast, (``--sync-bn``) one ``[T, C, 2]`` fp64 all-reduce per BatchNorm layer forward and one backward, the early
+    neck + head gradient all-reduce from the backward hook, the backbone part + join in ``all_reduce()`` - over fake
+    rank-specific gradients (the kernels need a GPU; the exchange plumbing does not).  A rank that issued another sequence
+    would hang (the tests run this under a timeout); the summed gradient must come out identical on every rank."""
     import torch.distributed as dist
-    backend = None
-    seen = 1
+    backend, seen, equal, n_coll, overlapped = None, 1, None, 0, False
+    cfg = CONFIGS[args.config]
+    T = args.timesteps or cfg["T"]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("SNN_DIST_BACKEND", "gloo"))
@@ -238,13 +330,49 @@ def dry_run(args, world: int, rank: int) -> None:
         t = torch.ones(1)
         dist.all_reduce(t)
         seen = int(t.item())
+        from snn_for_object_detection_amd.trainer import FlatTrainer, broadcast_parameters, convert_sync_batchnorm
+        classes = args.classes if args.classes is not None else cfg["classes"]
+        model, lr = build_model(args, cfg, classes, "cpu")
+        with torch.no_grad():                       # ranks start apart; the broadcast must bring them together
+            for p in model.parameters():
+                p.add_(0.01 * rank)
+        trainer = FlatTrainer(model, lr=lr, find_unused_parameters=False)
+        broadcast_parameters(trainer)
+        n_coll += 1
+        if args.sync_bn:
+            convert_sync_batchnorm(model)
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d) and getattr(m, "_snn_sync_group", None)]
+        overlapped = trainer._early_lo is not None
+        for it in range(2):
+            trainer.zero_grad()
+            for m in bns:                           # forward: statistics of the global batch, one exchange per layer
+                dist.all_reduce(torch.full((T, m.num_features, 2), float(rank), dtype=torch.float64),
+                                group=m._snn_sync_group[0])
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            trainer.flat_grad.copy_(torch.randn(trainer.flat_grad.shape, generator=g))
+            for slot in trainer.slots:
+                slot.written = True
+            hook = getattr(model, "_snn_neck_grads_ready", None)
+            if hook is not None:                    # the backward pass crosses the backbone / neck boundary
+                hook()
+            for m in reversed(bns):                 # backward: the BatchNorm-backward sums of the global batch
+                dist.all_reduce(torch.full((T, m.num_features, 2), float(rank), dtype=torch.float64),
+                                group=m._snn_sync_group[0])
+            trainer._written_flags()
+            trainer.all_reduce()
+            n_coll = 1 + 2 * len(bns) + (2 if overlapped else 1)
+        equal = replicas_equal(trainer, dist, "flat_grad") and replicas_equal(trainer, dist, "flat_param")
         dist.barrier()
     if rank == 0:
         emit_json({"metric": "event-frames/sec (BxT) SODa-3M GEN1 304x240 fwd+bwd", "value": None,
                    "unit": "event-frames/s", "n_gpus": world, "dry_run": True,
-                   "dist": {"backend": backend, "world_size": world, "ranks_in_allreduce": seen}})
+                   "config": {"name": args.config, "sync_batchnorm": bool(args.sync_bn and world > 1)},
+                   "dist": {"backend": backend, "world_size": world, "ranks_in_allreduce": seen,
+                            "replicas_equal_after_run": equal, "collectives_per_step": n_coll,
+                            "overlapped_gradient_exchange": overlapped}})
     if world > 1:
         dist.destroy_process_group()
+    return 0 if (equal is None or equal) else 3
 
 
 def main():
@@ -306,7 +434,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     reserve_stdout()
     if args.dry_run:
-        return dry_run(args, world, rank)
+        raise SystemExit(dry_run(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     if world > torch.cuda.device_count() and os.environ.get("SNN_DIST_BACKEND", "nccl") == "nccl":
@@ -345,27 +473,18 @@ def main():
     S.functional.set_activation_storage(args.storage)
     sb = args.storage == "bf16"
 
-    torch.manual_seed(2)  # same reference init on every rank
     X, labels = synthetic_batch(T, B, H, W, classes, device, seed=rank, p=cfg["p"])  # a different shard per rank
+    model, lr = build_model(args, cfg, classes, device)   # same reference init on every rank
     if args.config == "deep12":
-        model = S.BlockGen(2, deep12_cfg())
-        for m in model.modules():
-            if isinstance(m, torch.nn.Conv2d):
-                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-        model = model.to(device).train()
         probe = deep12_probe(B, H, W, device)
 
         def loss_fn():
             # the loss reads the spikes of the last timestep only (as the detector does, models/soda.py:141-144)
             out, _ = model(X, last_only=True)
             return (out * probe).mean()
-        lr = 1e-3
     else:
-        model = S.TinyYolo(num_classes=classes, time_window=0).to(device).train()
-
         def loss_fn():
             return model.training_step((X, labels))
-        lr = model.hparams.learning_rate
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     # find_unused_parameters=False is what the reference's `strategy: ddp` means (config/config.yaml:35): every rank
     # produces every gradient, so the step carries no used-parameter flag exchange
@@ -403,15 +522,11 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
     frames_per_s = world * B * T * steps / elapsed
-    replicas_equal = None
+    replicas_eq = None
     if distributed:
         # evidence that the gradient exchange kept the replicas together: after `warmup + steps` updates every rank
         # holds the same weights (ranks saw different shards, so a missing or partial all-reduce would show here)
-        chk = trainer.flat_param.double().abs().sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        replicas_equal = bool((lo == hi).item())
+        replicas_eq = replicas_equal(trainer, dist)
     peak_gib = torch.cuda.max_memory_allocated() / 2**30
 
     roofline = None
@@ -435,15 +550,7 @@ def main():
         default_shape = (T, B, H, W, classes) == (cfg["T"], cfg["batch"], cfg["H"], cfg["W"], cfg["classes"])
         traffic, traffic_src = (pmc_traffic(args.config + ("_bf16s" if sb else ""), name) if default_shape
                                 else (None, {"note": "non-default shape"}))
-        if name.startswith("k_conv"):
-            peak, peak_note = mfma_peak_for(name, args.forward_precision, args.backward_precision)
-            head = {"bound": "mfma", "kernel": name, "achieved": row["tflops"], "peak": peak, "peak_basis": peak_note,
-                    "unit": "TFLOP/s", "frac": row["tflops"] / peak}
-        else:  # the fused norm + neuron scans and the other pointwise kernels move bytes: priced against HBM
-            head = {"bound": "hbm", "kernel": name, "achieved": row["gbs"], "peak": PEAK_HBM_GBS,
-                    "peak_basis": f"HBM3E 8 TB/s spec (6.3 TB/s measured copy rate); algorithmic bytes = {2 if sb else 4} B per "
-                                  "tensor element the fused kernel must touch", "unit": "GB/s",
-                    "frac": row["gbs"] / PEAK_HBM_GBS}
+        head = roofline_head(name, row, args.forward_precision, args.backward_precision, sb)
         roofline = {
             **head, "traffic": traffic, "traffic_source": traffic_src,
             "achieved_tflops": row["tflops"], "achieved_hbm_gbs": row["gbs"], "frac_hbm": row["gbs"] / PEAK_HBM_GBS,
@@ -458,8 +565,10 @@ def main():
                 {"kernel": k, "ms_per_step": r["ms"] / 2, "share": r["ms"] / total_ms, "launches_per_step": r["calls"] // 2,
                  "tflops": r["tflops"], "gbs": r["gbs"], "frac_hbm": r["gbs"] / PEAK_HBM_GBS,
                  "frac_mfma": (r["tflops"] / mfma_peak_for(k, args.forward_precision, args.backward_precision)[0]
-                               if k.startswith("k_conv") else None)}
-                for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if r["ms"] / total_ms >= 0.02],
+                               if k.startswith("k_conv") else None),
+                 "bound": roofline_head(k, r, args.forward_precision, args.backward_precision, sb)["bound"]}
+                for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if r["ms"] / total_ms >= 0.02]
+                + [c for c in [chain_row(table, prof.neuron_steps, 2, sb)] if c],
             "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream off",
         }
         if args.kernel_table:
@@ -470,7 +579,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
+        # every core this process may use, capped at 16 = one GPU's share of the box (the driver runs one bench per GPU;
+        # `cores`, the host's total and the CPU model are all in the line)
+        threads = min(host_cpu()["cores_available_to_process"] or 1, 16)
         cpu = cpu_baseline(args.config, H, W, classes, threads, cfg["p"])  # bounded sample: about 10-30 s of CPU work
 
     if distributed:
@@ -486,6 +597,9 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": ms_per_step,
+            # independent of n_gpus (weak scaling: every rank steps the same per-GPU batch): compare SCALE's N=1 line
+            # with BENCH, and any N with any other, at a glance
+            "per_gpu": {"event_frames_per_s": frames_per_s / world, "batch": B, "ms_per_step": ms_per_step},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -530,7 +644,7 @@ def main():
                                            "pass), backbone part in step()" if getattr(trainer, "_early_lo", None)
                                            else "one SUM all-reduce of the flat fp32 gradient per step")
                      if distributed else None,
-                     "replicas_equal_after_run": replicas_equal,
+                     "replicas_equal_after_run": replicas_eq,
                      # (device, candidates probed, runs beside the main stream?) for the weight-gradient and the
                      # communication stream: HIP streams share a few hardware queues, see functional.concurrent_stream
                      "side_streams_probed": S.functional._STREAM_PROBE_LOG,
@@ -552,6 +666,10 @@ def main():
         emit_json(out)
     if distributed:
         dist.destroy_process_group()
+    if replicas_eq is False:
+        # an N > 1 line whose replicas drifted apart measured something else than data-parallel training: never exit 0
+        raise SystemExit("bench.py: replicas differ after the run (replicas_equal_after_run false): the gradient exchange "
+                         "did not keep the ranks together")
 
 
 if __name__ == "__main__":

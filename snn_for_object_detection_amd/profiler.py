@@ -141,9 +141,12 @@ class KernelProfiler:
 
     def __init__(self):
         self.records = []
+        self.neuron_steps = 0.0   # neuron-timesteps (elements x T) of the forward scans seen: the unit SURVEY 8(d) prices
 
     def before(self, name, args):
         label, flops, byts = work_of(name, args)
+        if name in ("snn_affine_neuron_fwd", "snn_lif_fwd_ckpt"):
+            self.neuron_steps += flops / 12.0   # work_of counts 12 FLOP per neuron-timestep
         start = torch.cuda.Event(enable_timing=True)
         end = torch.cuda.Event(enable_timing=True)
         start.record()

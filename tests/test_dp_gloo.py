@@ -218,3 +218,36 @@ def test_bench_gpus2_starts_two_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,flags", [(4, ["--config", "gen1"]), (8, ["--config", "gen1", "--sync-bn"]),
+                                         (4, ["--config", "deep12"]), (8, ["--config", "deep12", "--sync-bn"])],
+                         ids=["w4-gen1", "w8-gen1-syncbn", "w4-deep12", "w8-deep12-syncbn"])
+def test_bench_dry_run_rehearses_every_collective_of_the_step_at_world_4_and_8(world, flags):
+    """The first real N > 1 run happens on the driver's 8-GPU node: ``--dry-run`` walks the REAL model and trainer of the
+    workload through every collective of the step (weight broadcast, SyncBatchNorm exchanges per layer, early neck + head
+    all-reduce from the backward hook, backbone part + join) on gloo; a rank out of sequence hangs (timeout), a missing
+    exchange leaves the replicas apart (non-zero exit)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNN_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run", *flags],
+                         env=env, capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    d = out["dist"]
+    assert out["n_gpus"] == world and d["world_size"] == world and d["ranks_in_allreduce"] == world
+    assert d["replicas_equal_after_run"] is True
+    sync = "--sync-bn" in flags
+    assert out["config"] == {"name": flags[1], "sync_batchnorm": sync}
+    n_bn = {"gen1": 22, "deep12": 12}[flags[1]] if sync else 0
+    gen1 = flags[1] == "gen1"
+    assert d["overlapped_gradient_exchange"] is gen1               # SODa: neck + head go out from the backward hook
+    assert d["collectives_per_step"] == 1 + 2 * n_bn + (2 if gen1 else 1)

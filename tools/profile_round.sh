@@ -6,9 +6,11 @@
 #                                   on the GPU: the per-kernel averages behind roofline.frac)
 #   stats2/s_kernel_stats.csv     : the same with the side stream ON (the step as it really runs)
 #   traffic.json                  : per-kernel HBM bytes from two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE)
+#   traffic_counters.csv          : the same two passes summed per kernel NAME (what traffic.json is recomputed from)
 #   mfma.json                     : matrix pipe / VALU / LDS / TA utilisation per kernel family (three more --pmc passes)
 tag=${1:-prof}
 cfg=${2:-gen1}
+ROUND=${ROUND:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
@@ -28,10 +30,12 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
     python3 bench.py $P > /dev/null 2> $out/f.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -o w -- \
     python3 bench.py $P > /dev/null 2> $out/w.err || exit 1
-python tools/pmc_traffic.py $(find $out/pmc_f -name 'f_counter_collection.csv') $(find $out/pmc_w -name 'w_counter_collection.csv') $out/traffic.json 3 ${sfx#_} > $out/traffic.txt
+python tools/pmc_traffic.py $(find $out/pmc_f -name 'f_counter_collection.csv') $(find $out/pmc_w -name 'w_counter_collection.csv') $out/traffic.json 3 ${sfx#_} $out/traffic_counters.csv > $out/traffic.txt
+[ -z "$sfx" ] && sed -i 's/"counters": "traffic_counters.csv"/"counters": "'$ROUND'_pmc_counters_'$cfg'.csv"/' $out/traffic.json
+[ -n "$sfx" ] && sed -i 's/"counters": "traffic_counters.csv"/"counters": "'$ROUND'_pmc_counters_'$cfg$sfx'.csv"/' $out/traffic.json
 # the bench line of this round quotes THESE passes: put the file where bench.py looks for it (tools/collect_profiles.sh
 # copies the same file to the same place in the repository afterwards)
-cp $out/traffic.json profiles/r03_pmc_traffic_$cfg$sfx.json
+cp $out/traffic.json profiles/${ROUND}_pmc_traffic_$cfg$sfx.json
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d $out/pmc_a -o a -- python3 bench.py $P > /dev/null 2> $out/a.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
