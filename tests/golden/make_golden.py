@@ -153,6 +153,129 @@ def sli_synapse_golden(gen):
     np.savez_compressed(os.path.join(OUT, "synapse.npz"), **out)
 
 
+def events_golden():
+    """``utils/datasets.py``: ``STPropheseeDataset.parse_data`` (:378-435), ``MTPropheseeDataset.parse_data`` (:311-344) and
+    ``PropheseeDataModule._stack_data`` (:127-135) - the step FEEDING the hot path - executed
+    unmodified.  The module imports ``lightning`` (base class of the data module) and
+    ``prophesee_toolbox.src.io.psee_loader.PSEELoader`` (the recording reader, an un-fetched submodule) at import time
+    only; empty stand-in modules satisfy both imports, and the method bodies see a FAKE loader - an object with the three
+    members they use (``done``, ``current_time``, ``load_delta_t``) that serves a seeded structured ``(t, x, y, p)``
+    array - so what is pinned is the reference's own binning / clipping / flagging / label selection / padding, as DATA
+    (``events.npz``: the event stream, the boxes, and the non-zero cells + labels that came out)."""
+    lightning = types.ModuleType("lightning")
+    lightning.LightningDataModule = type("LightningDataModule", (), {"__init__": lambda self, *a, **k: None})
+    loader_mod = types.ModuleType("prophesee_toolbox.src.io.psee_loader")
+    loader_mod.PSEELoader = type("PSEELoader", (), {})
+    names = ("lightning", "prophesee_toolbox", "prophesee_toolbox.src", "prophesee_toolbox.src.io",
+             "prophesee_toolbox.src.io.psee_loader")
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules["lightning"] = lightning
+    for k in names[1:-1]:
+        m = types.ModuleType(k)
+        m.__path__ = []
+        sys.modules[k] = m
+    sys.modules[names[-1]] = loader_mod
+    try:
+        ds = _load("ref_datasets", os.path.join(REF, "utils", "datasets.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    class FakeLoader:
+        """Serves ``events`` (sorted by t) the way the methods consume a recording: ``load_delta_t(d)`` returns the events
+        of ``[current_time, current_time + d)`` and advances the clock; ``done`` once the stream is exhausted."""
+
+        def __init__(self, events, start_us, end_us):
+            self.events, self.current_time, self.end = events, int(start_us), int(end_us)
+
+        @property
+        def done(self):
+            return self.current_time >= self.end
+
+        def reset(self):
+            self.current_time = 0
+
+        def load_delta_t(self, delta):
+            lo, hi = self.current_time, self.current_time + int(delta)
+            self.current_time = hi
+            t = self.events["t"]
+            return self.events[(t >= lo) & (t < hi)].copy()
+
+    def stream(rng, n, t_lo, t_hi, width, height, x_over):
+        ev = np.zeros(n, dtype=[("t", "<i8"), ("x", "<i4"), ("y", "<i4"), ("p", "<i4")])
+        ev["t"] = np.sort(rng.integers(t_lo, t_hi, n))
+        ev["x"] = rng.integers(0, width + x_over, n)        # x past the frame: the 1Mpx quirk parse_data clips (:425-426)
+        ev["y"] = rng.integers(0, height, n)
+        ev["p"] = rng.integers(0, 2, n)
+        return ev
+
+    out = {}
+    rng = np.random.default_rng(77)
+    # ---- single-target samples (training): GEN1 frame and a 1Mpx frame with out-of-frame x
+    st_cases = (("st_gen1", "gen1", 4, 2, 16, 70_000, 0), ("st_1mpx", "1mpx", 3, 1, 16, 40_000, 9),
+                ("st_sparse", "gen1", 4, 2, 16, 900, 0))
+    for tag, name, T, shift, step_ms, n_events, x_over in st_cases:
+        d = ds.STPropheseeDataset(num_steps=T, time_shift=shift, gt_files=["g"], data_files=["d"], time_step=step_ms,
+                                  num_load_file=1, name=name)
+        step_us = d.time_step_us
+        start_us = 3 * step_us + 1234                          # the recording clock is not on a step boundary
+        start_step = start_us // step_us
+        # boxes (step, class, x1, y1, x2, y2): rows BEFORE start_step + T are skipped, the first later step's rows are
+        # the sample's labels, a box below the 1 % area threshold is dropped, later steps are ignored
+        s0 = start_step + T + 2
+        gt = torch.tensor([[start_step + 1, 0, 0.1, 0.1, 0.5, 0.5], [s0, 1, 0.20, 0.25, 0.60, 0.70],
+                           [s0, 0, 0.40, 0.40, 0.45, 0.45], [s0, 0, 0.05, 0.30, 0.55, 0.95],
+                           [s0 + 5, 1, 0.3, 0.3, 0.9, 0.9]], dtype=torch.float32)
+        ev = stream(rng, n_events, start_us, (s0 + shift + 2) * step_us, d._width, d._height, x_over)
+        loader = FakeLoader(ev, start_us, 10 ** 9)
+        sample, more = d.parse_data(gt.clone(), loader)
+        out.update({f"{tag}_events_t": ev["t"], f"{tag}_events_x": ev["x"], f"{tag}_events_y": ev["y"],
+                    f"{tag}_events_p": ev["p"], f"{tag}_gt": gt.numpy(),
+                    f"{tag}_params": np.array([T, shift, step_us, start_us, d._height, d._width, d.events_threshold]),
+                    f"{tag}_box_size_threshold": d.box_size_threshold,
+                    f"{tag}_more": bool(more), f"{tag}_clock_after": loader.current_time,
+                    f"{tag}_rejected": sample is None})
+        if sample is not None:
+            feats, labels = sample
+            assert feats.shape == (T, 2, d._height, d._width) and set(feats.unique().tolist()) <= {0.0, 1.0}
+            out[f"{tag}_nonzero"] = np.flatnonzero(feats.numpy().reshape(-1)).astype(np.int64)
+            out[f"{tag}_labels"] = labels.numpy()
+    # ---- multi-target sample (evaluation)
+    T, step_ms = 5, 16
+    d = ds.MTPropheseeDataset(num_steps=T, gt_files=["g"], data_files=["d"], time_step=step_ms, num_load_file=1, name="gen1")
+    step_us = d.time_step_us
+    # (the evaluation reader starts at 0 and advances by whole windows: its clock is always on a step boundary - off one,
+    #  the events of the last partial step index frame T and the reference raises IndexError)
+    start_us = 7 * step_us
+    start_step = start_us // step_us
+    gt = torch.tensor([[start_step - 1, 0, 0.1, 0.1, 0.5, 0.5], [start_step, 1, 0.2, 0.2, 0.6, 0.7],
+                       [start_step + 2, 0, 0.3, 0.1, 0.7, 0.4], [start_step + T - 1, 1, 0.5, 0.5, 0.9, 0.9],
+                       [start_step + T, 0, 0.1, 0.6, 0.3, 0.9]], dtype=torch.float32)
+    ev = stream(rng, 30_000, start_us, start_us + (T + 2) * step_us, d._width, d._height, 0)
+    loader = FakeLoader(ev, start_us, 10 ** 9)
+    feats, labels = d.parse_data(gt.clone(), loader)
+    out.update({"mt_events_t": ev["t"], "mt_events_x": ev["x"], "mt_events_y": ev["y"], "mt_events_p": ev["p"],
+                "mt_gt": gt.numpy(), "mt_params": np.array([T, 0, step_us, start_us, d._height, d._width, 0]),
+                "mt_clock_after": loader.current_time,
+                "mt_nonzero": np.flatnonzero(feats.numpy().reshape(-1)).astype(np.int64), "mt_labels": labels.numpy()})
+    # an empty window: the features stay zero and the label set is EMPTY (:328-329)
+    empty = FakeLoader(ev[:0], start_us, 10 ** 9)
+    feats0, labels0 = d.parse_data(gt.clone(), empty)
+    out.update({"mt_empty_nonzero_count": int(feats0.count_nonzero()), "mt_empty_labels_shape": np.array(labels0.shape)})
+    # ---- collate: ragged label lists padded with -1, features stacked on dim 1 (:127-135)
+    g = torch.Generator().manual_seed(5)
+    batch = [((torch.rand(3, 2, 4, 6, generator=g) < 0.2).float(), torch.rand(n, 5, generator=g)) for n in (2, 0, 3)]
+    features, targets = ds.PropheseeDataModule._stack_data(None, batch)
+    for b, (f, l) in enumerate(batch):
+        out[f"stack_features_{b}"] = f.numpy()
+        out[f"stack_labels_{b}"] = l.numpy()
+    out.update({"stack_out_features": features.numpy(), "stack_out_targets": targets.numpy()})
+    np.savez_compressed(os.path.join(OUT, "events.npz"), **out)
+
+
 def tiny_yolo_description():
     """Execute ``models/tiny_yolo.py`` with recording stand-ins for ``models.soda.SODa`` / ``models.generator`` /
     ``models.modules`` (the real ones need Lightning, norse and python >= 3.12): the file only BUILDS nested lists of
@@ -285,6 +408,7 @@ def main():
                         offsets=offp.numpy(), detections=det.numpy())
     convlstm_golden(gen)
     sli_synapse_golden(gen)
+    events_golden()
     tiny_yolo_description()
     print("golden vectors written to", OUT)
 

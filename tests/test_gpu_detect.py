@@ -126,6 +126,41 @@ def test_event_batcher_matches_oracle_and_feeds_the_model(pkg):
     assert all(torch.equal(u, v) for u, v in zip(a, b))
 
 
+def test_event_batcher_matches_reference_generated_fixture(pkg, golden_dir):
+    """``k_events`` / ``EventBatcher`` against the REFERENCE's own voxelisation (``tests/golden/events.npz``: outputs of
+    ``utils/datasets.py`` ``parse_data`` / ``_stack_data`` executed unmodified by ``make_golden.py``) - no oracle in
+    between: the batcher is handed the raw event stream and the window start the reference derived, and must set exactly
+    the cells the reference set (GEN1 and 1 Mpx with x past the frame; the multi-target window), labels padded with -1."""
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "events.npz"))
+
+    def case(tag):
+        T, shift, step_us, clock, H, W, _ = (int(v) for v in z[f"{tag}_params"])
+        ev = tuple(torch.from_numpy(z[f"{tag}_events_{k}"].astype(np.int64)).pin_memory() for k in "txyp")
+        return T, shift, step_us, clock, H, W, ev
+
+    for tag in ("st_gen1", "st_1mpx"):
+        T, shift, step_us, clock, H, W, ev = case(tag)
+        # the window the reference's parse_data chose (datasets.py:408-411): first labelled step at or after
+        # start_step + T, moved back by T - time_shift steps
+        gt = z[f"{tag}_gt"]
+        first = gt[gt[:, 0] >= clock // step_us + T][0, 0]
+        t0 = int(first) * step_us - step_us * (T - shift)
+        X, lab = pkg.EventBatcher(T, H, W, step_us)([ev + (t0,)], [torch.from_numpy(z[f"{tag}_labels"])])
+        got = np.flatnonzero(X[:, 0].contiguous().cpu().numpy().reshape(-1))
+        assert np.array_equal(got, z[f"{tag}_nonzero"]), tag
+        assert float(X.sum()) == len(z[f"{tag}_nonzero"])            # flags, not counts
+        assert torch.equal(lab[0].cpu(), torch.from_numpy(z[f"{tag}_labels"]))
+    T, _, step_us, clock, H, W, ev = case("mt")                       # multi-target: bins count from the window's first step
+    X = pkg.EventBatcher(T, H, W, step_us)([ev + ((clock // step_us) * step_us,)])
+    assert np.array_equal(np.flatnonzero(X[:, 0].contiguous().cpu().numpy().reshape(-1)), z["mt_nonzero"])
+    # collate of ragged label lists (one sample without a box): the reference's padded targets
+    labs = [torch.from_numpy(z[f"stack_labels_{b}"]) for b in range(3)]
+    empty = tuple(torch.zeros(0, dtype=torch.int64) for _ in range(4)) + (0,)
+    _, lab = pkg.EventBatcher(3, 4, 6, 1000)([empty] * 3, labs)
+    assert torch.equal(lab.cpu(), torch.from_numpy(z["stack_out_targets"]))
+
+
 def test_roi_assign_kernel_matches_reference_vectors(hip_lib, golden_dir):
     """snn_roi_assign (one block per sample) against vectors produced by the reference's own utils/roi.py: class labels
     and masks bit for bit (plain labels and labels with -1 padding rows: the reference gives every padding ROW an

@@ -130,3 +130,44 @@ def test_oracle_synapse_matches_reference_vectors(golden_dir):
         assert torch.equal(state[0].detach(), torch.from_numpy(z[f"p_final_{tag}"]))
         (gs * torch.from_numpy(z["gg"])).sum().backward()
         assert torch.allclose(x.grad, torch.from_numpy(z[f"gx_{tag}"]), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- event feed
+def _events_case(z, tag):
+    T, shift, step_us, clock, H, W, thr = (int(v) for v in z[f"{tag}_params"])
+    ev = tuple(z[f"{tag}_events_{k}"] for k in "txyp")
+    return T, shift, step_us, clock, H, W, thr, ev, z[f"{tag}_gt"]
+
+
+def test_oracle_event_voxelisation_matches_reference_vectors(golden_dir):
+    """``oracle/events.py`` against what the reference's OWN ``parse_data`` / ``_stack_data`` produced
+    (``tests/golden/events.npz``, written by ``make_golden.py::events_golden`` from ``utils/datasets.py:311-344,378-435,
+    127-135`` executed unmodified): non-zero cells, labels, the recording clock afterwards and the rejection of a sparse
+    window, bit for bit - single-target GEN1, single-target 1 Mpx with events past the frame (clipped), multi-target."""
+    from oracle import events as OE
+    z = np.load(os.path.join(golden_dir, "events.npz"))
+    for tag in ("st_gen1", "st_1mpx", "st_sparse"):
+        T, shift, step_us, clock, H, W, thr, ev, gt = _events_case(z, tag)
+        sample, more, clock_after, _ = OE.st_sample(gt, *ev, clock, T, shift, step_us, H, W, thr,
+                                                    float(z[f"{tag}_box_size_threshold"]))
+        assert more == bool(z[f"{tag}_more"]) and clock_after == int(z[f"{tag}_clock_after"]), tag
+        assert (sample is None) == bool(z[f"{tag}_rejected"]), tag
+        if sample is not None:
+            feats, labels = sample
+            assert feats.shape == (T, 2, H, W) and feats.dtype == np.float32
+            assert np.array_equal(np.flatnonzero(feats.reshape(-1)), z[f"{tag}_nonzero"]), tag
+            assert set(np.unique(feats)) <= {0.0, 1.0}
+            assert np.array_equal(labels, z[f"{tag}_labels"]), tag
+    assert bool(z["st_sparse_rejected"]) and not bool(z["st_gen1_rejected"])     # the fixture exercises both outcomes
+    assert int(z["st_1mpx_events_x"].max()) > 1279                                 # ... and the clip of x past the frame
+    T, _, step_us, clock, H, W, _, ev, gt = _events_case(z, "mt")
+    feats, labels, clock_after = OE.mt_sample(gt, *ev, clock, T, step_us, H, W)
+    assert np.array_equal(np.flatnonzero(feats.reshape(-1)), z["mt_nonzero"]) and clock_after == int(z["mt_clock_after"])
+    assert np.array_equal(labels, z["mt_labels"])
+    feats0, labels0, _ = OE.mt_sample(gt, *(e[:0] for e in ev), clock, T, step_us, H, W)
+    assert int(np.count_nonzero(feats0)) == int(z["mt_empty_nonzero_count"]) == 0
+    assert tuple(labels0.shape) == tuple(z["mt_empty_labels_shape"])
+    # collate: ragged label lists (one sample without a box) padded with -1
+    samples = [(z[f"stack_features_{b}"], z[f"stack_labels_{b}"]) for b in range(3)]
+    feats, targets = OE.stack_batch(samples)
+    assert np.array_equal(feats, z["stack_out_features"]) and np.array_equal(targets, z["stack_out_targets"])

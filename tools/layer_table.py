@@ -23,6 +23,8 @@ from snn_for_object_detection_amd.trainer import FlatTrainer  # noqa: E402
 def shape_of(name, a):
     if name in ("snn_conv2d_fwd", "snn_conv2d_dgrad"):
         a = tuple(a[:3]) + tuple(a[4:])   # without the pre-split weight pointer: the positions snn_conv2d_wgrad has
+    if name == "snn_conv2d_wgrad_bn":   # (x, gx, y, the four coefficient rows, ... first: geometry starts at position 10)
+        return f"N{a[10]} {a[11]}x{a[12]} {a[13]}->{a[16]} k{a[17]} s{a[19]} +bn-apply"
     if name.startswith("snn_conv2d"):
         return f"N{a[5]} {a[6]}x{a[7]} {a[8]}->{a[11]} k{a[12]} s{a[14]}"
     if name == "snn_conv3x3_halo":
