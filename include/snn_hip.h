@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 8
+#define SNN_ABI_VERSION 9
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -374,9 +374,11 @@ int snn_small_gemm(const float* A, int64_t lda, int transA, const float* B, int6
                   int64_t ldc, int M, int N, int K, int accumulate, float* Ct, int64_t ldct, void* stream);
 /* n products C_i = A_i B_i of dense row-major matrices (A_i [M,K], B_i [K,N], C_i [M,N]; Ct_i [N,M] = the transposed copy,
  * base_ct may be NULL) in ONE launch: the composed 1x1 weights w2 w1 of every C2f entry (reference models/tiny_yolo.py:76-82)
- * once per optimiser step.  `table` (device): n rows {A offset, B offset, C offset, Ct offset, M, N, K} as int64, offsets in
- * floats relative to the four base pointers; max_tiles >= ceil(M/32) * ceil(N/32) of every row.  Same fmaf chains (k order)
- * as snn_small_gemm. */
+ * once per optimiser step.  `table` (device): n rows {A offset, B offset, C offset, Ct offset, M, N, K, ldct} as int64 (ABI
+ * v9: 8 columns), offsets in floats relative to the four base pointers; ldct = row length of the transposed copy (0 = M):
+ * several products may write column blocks of ONE [N][sum M] matrix - the row-stacked weight of sibling 1x1 convolutions
+ * (models/tiny_yolo.py:84-85) and its transpose; max_tiles >= ceil(M/32) * ceil(N/32) of every row.  Same fmaf chains
+ * (k order) as snn_small_gemm. */
 int snn_small_gemm_batched(const float* base_a, const float* base_b, float* base_c, float* base_ct, const int64_t* table,
                            int n, int max_tiles, void* stream);
 

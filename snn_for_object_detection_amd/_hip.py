@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE = 1, 2, 4
 

@@ -440,18 +440,20 @@ __global__ __launch_bounds__(kThreads) void k_small_gemm(const float* __restrict
 }
 
 // n independent products C_i = A_i B_i (+ the transposed copy) in one launch: table row {A offset, B offset, C offset, Ct
-// offset, M, N, K} in floats relative to base_a / base_b / base_c / base_ct; blockIdx.y = the product, blockIdx.x = its tile
-// (blocks past a product's last tile leave at once).  Dense row-major operands.
+// offset, M, N, K, ldct} in floats relative to base_a / base_b / base_c / base_ct; blockIdx.y = the product, blockIdx.x = its
+// tile (blocks past a product's last tile leave at once).  Dense row-major operands; ldct (0 = M) lets several products
+// write column blocks of ONE transposed matrix (row-stacked sibling weights).
 __global__ __launch_bounds__(kThreads) void k_small_gemm_batched(const float* __restrict__ base_a,
                                                                  const float* __restrict__ base_b,
                                                                  float* __restrict__ base_c, float* __restrict__ base_ct,
                                                                  const int64_t* __restrict__ table) {
-    const int64_t* row = table + (int64_t)blockIdx.y * 7;
+    const int64_t* row = table + (int64_t)blockIdx.y * 8;
     const int M = (int)row[4], N = (int)row[5], K = (int)row[6];
+    const int64_t ldct = row[7] > 0 ? row[7] : M;
     const int tn = (N + 31) / 32, tm = (M + 31) / 32;
     if ((int)blockIdx.x >= tn * tm) return;   // whole block, before any barrier
     small_gemm_tile<false, false>(base_a + row[0], K, base_b + row[1], N, base_c + row[2], N, M, N, K, 0,
-                                  base_ct ? base_ct + row[3] : nullptr, M, ((int)blockIdx.x / tn) * 32,
+                                  base_ct ? base_ct + row[3] : nullptr, ldct, ((int)blockIdx.x / tn) * 32,
                                   ((int)blockIdx.x % tn) * 32);
 }
 

@@ -466,6 +466,8 @@ def flush_counter_batch() -> None:
 
 
 FUSE_OUTER_ADDEND = not os.environ.get("SNN_NO_OUTER_ADDEND")  # bisecting aid
+# sibling 1x1 convolutions of one input (the C2f split) as ONE convolution (generator.BlockGen._plan_siblings)
+USE_SIBLING_FUSION = not os.environ.get("SNN_NO_SIBLING_FUSION")
 
 
 class GradAccumulator:
@@ -473,7 +475,7 @@ class GradAccumulator:
     convolution that runs for the fanned-out tensor add the gradients other branches have already produced
     in its epilogue (``snn_conv2d_dgrad(addend=...)``) instead of a separate add pass afterwards."""
 
-    __slots__ = ("deposits", "result", "fused", "outer")
+    __slots__ = ("deposits", "result", "fused", "outer", "exclusive", "grad_in_slot")
 
     def __init__(self):
         self.deposits = {}    # alias index -> gradient produced for that alias by a pass-through consumer
@@ -481,10 +483,15 @@ class GradAccumulator:
         self.fused = {}       # alias index -> deposit that went into ``result``
         self.outer = None     # (accumulator, alias index) of the enclosing fanout when the fanned-out tensor is
         #                       itself an alias (Residual inside Dense: the YOLO bottleneck)
+        self.exclusive = set()    # keys whose deposit nobody else reads (a channel slice of a concat gradient handed to
+        #                           exactly this consumer): the accumulated gradient may be written over it
+        self.grad_in_slot = False  # the fanned-out tensor wants its total gradient left IN such a slice (split_channels)
 
-    def deposit(self, key, g: torch.Tensor) -> None:
+    def deposit(self, key, g: torch.Tensor, exclusive: bool = False) -> None:
         if self.result is None and g is not None:
             self.deposits[key] = g
+            if exclusive:
+                self.exclusive.add(key)
 
 
 def _acc_of(x):
@@ -504,14 +511,14 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
     """Data gradient of a convolution with the gradient accumulation of its input folded into the epilogue
     (up to two addends; see ``GradAccumulator``).  ``wt`` is the transposed weight ``[Cin][KH][KW][Cout]``."""
     T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad = geom
-    dx = _new_cl((T, B), Cin, H, W, x)
+    dx, dx_shape = None, (T, B, Cin, H, W)
     addend, ld_add, addend2, ld_add2 = None, 0, None, 0
     outer_fused = None
     if acc is not None and acc[0].result is None and acc[0].deposits:
         # another branch of the block already produced its gradient for this tensor: add it here
         key, other = next(iter(acc[0].deposits.items()))
         other = _raw_to_cl(other)
-        if tuple(other.shape) == tuple(dx.shape):
+        if tuple(other.shape) == dx_shape:
             addend, ld_add = other.data_ptr(), cl_stride(other)
             acc[0].fused[key] = acc[0].deposits.pop(key)
     if (acc is not None and acc[0].result is None and not acc[0].deposits and acc[0].outer is not None
@@ -522,40 +529,49 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
         if o_acc.result is None and len(o_acc.deposits) == 1 and o_key not in o_acc.deposits:
             key2, other2 = next(iter(o_acc.deposits.items()))
             other2 = _raw_to_cl(other2)
-            if tuple(other2.shape) == tuple(dx.shape):
+            if tuple(other2.shape) == dx_shape:
                 addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
                 outer_fused = (o_acc, o_key, key2)
+                if (o_acc.grad_in_slot and key2 in o_acc.exclusive and other2.dtype == x.dtype and ld_add2 % 4 == 0
+                        and USE_SIBLING_FUSION):
+                    # the total is written over the concat-gradient slice it contains (every kernel's epilogue reads an
+                    # addend element and stores the sum from the same lane): the gradient of a split_channels part then
+                    # lies next to its siblings' and the fused convolution reads them as ONE channel-sliced tensor
+                    dx = _alias(other2, other2.storage_offset(), T, B, Cin, H, W, ld_add2)
     chained = False
     if (acc is not None and acc[0].result is not None and addend is None and acc[1] not in acc[0].fused
-            and tuple(acc[0].result.shape) == tuple(dx.shape)):
+            and tuple(acc[0].result.shape) == dx_shape):
         # a sibling convolution already produced (its gradient + the fused deposits) for this tensor: add
         # that here and become the accumulated result (two convolutions on one input: the C2f split)
         prev = acc[0].result
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
+    if dx is None:
+        dx = _new_cl((T, B), Cin, H, W, x)
     if pend is not None:
         # (gy is gx here) dy = A*gx + B*y + C inside the halo-resident kernel, stored to pend[1] for the weight gradient
         rec, dy_out = pend
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
         _hip.call("snn_conv3x3_halo_bn", rec.gx.data_ptr(), rec.y.data_ptr(), rec.coef.data_ptr(), B, dy_out.data_ptr(),
-                  wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cout, Cin, addend, ld_add, addend2, ld_add2, st)
+                  wt_image.data_ptr(), dx.data_ptr(), cl_stride(dx), T * B, H, W, Cout, Cin, addend, ld_add, addend2, ld_add2,
+                  st)
     elif (prec in _HALO_BWD_PRECS and ldg % 4 == 0 and USE_HALO_CONV and (KH, KW, stride, pad) == (3, 3, 2, 1)
             and _hip.query("snn_conv3x3_s2_dgrad_supported", T * B, H, W, Cin, Ho, Wo, Cout)):
         # stride 2: all four phase classes of dx from ONE staged pass over dy (k_conv_s2dgrad3)
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
-        _hip.call("snn_conv3x3_s2_dgrad", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cin, Ho,
+        _hip.call("snn_conv3x3_s2_dgrad", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), cl_stride(dx), T * B, H, W, Cin, Ho,
                   Wo, Cout, addend, ld_add, addend2, ld_add2, prec, st)
     elif (prec in _HALO_BWD_PRECS and ldg % 4 == 0 and _halo_ok(T * B, H, W, Cout, Cin, KH, KW, stride, pad)):
         # dx = conv3x3(dy, mirrored taps of w^T): the halo-resident kernel with the data gradient's weight image
         if wt_image is None:
             wt_image = _frag_image(wt, Cin, Cout, 1, _hip.PREC_BF16X3)
-        _hip.call("snn_conv3x3_halo", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), Cin, T * B, H, W, Cout, Cin,
-                  addend, ld_add, addend2, ld_add2, None, 0, None, prec, st)
+        _hip.call("snn_conv3x3_halo", gy.data_ptr(), ldg, wt_image.data_ptr(), dx.data_ptr(), cl_stride(dx), T * B, H, W, Cout,
+                  Cin, addend, ld_add, addend2, ld_add2, None, 0, None, prec, st)
     else:
-        _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), wt_split, dx.data_ptr(), Cin, T * B, H, W, Cin,
-                  Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
+        _hip.call("snn_conv2d_dgrad", gy.data_ptr(), ldg, wt.data_ptr(), wt_split, dx.data_ptr(), cl_stride(dx), T * B, H, W,
+                  Cin, Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
     if acc is not None and (acc[0].result is None or chained):
         if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
             acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
@@ -789,13 +805,14 @@ class _Conv2d(Function):
 
 
 def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int,
-                ct: Optional[torch.Tensor] = None) -> None:
-    """``c (+)= op(a) @ op(b)`` on dense row-major fp32 matrices (``snn_small_gemm``, current stream); ``ct``
-    (``[n, m]``): the transposed result from the same launch."""
+                ct: Optional[torch.Tensor] = None, ct_col: int = 0) -> None:
+    """``c (+)= op(a) @ op(b)`` on dense row-major fp32 matrices (``snn_small_gemm``, current stream); ``ct``: the
+    transposed result from the same launch - ``[n, m]``, or columns ``ct_col .. ct_col + m`` of a wider ``[n, M]`` matrix."""
     m, n = c.shape
     k = a.shape[0] if trans_a else a.shape[1]
+    ct_ptr, ldct = (None, 0) if ct is None else (ct.data_ptr() + 4 * ct_col, ct.shape[1])
     _hip.call("snn_small_gemm", a.data_ptr(), a.shape[1], int(trans_a), b.data_ptr(), b.shape[1], int(trans_b),
-              c.data_ptr(), n, m, n, k, int(accumulate), _ptr(ct), m if ct is not None else 0, _stream())
+              c.data_ptr(), n, m, n, k, int(accumulate), ct_ptr, ldct, _stream())
 
 
 class _ComposedConv1x1(Function):
@@ -903,6 +920,191 @@ def composed_conv1x1(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dest: 
     y = _ComposedConv1x1.apply(seq, w1, w2, _slot_of(w1), _slot_of(w2), dest, _acc_of(seq),
                                _prec_codes(forward_precision, backward_precision))
     return y[0] if single else y
+
+
+class _SplitChannels(Function):
+    """Channel ranges of one channels-last tensor as separate tensors (aliases, no copy): the branch inputs behind a
+    fused sibling convolution.  Backward wants ONE gradient for the whole tensor: the parts ask (``_snn_grad_in_slot``)
+    that their accumulated gradients be left in the concat-gradient slices they contain (``_dgrad_accumulate``), which
+    for sibling outputs that sit side by side in a Dense merge are side by side too - then the gradients ARE one
+    channel-sliced tensor; otherwise they are gathered by the strided copy kernel."""
+
+    @staticmethod
+    def forward(ctx, x, widths):
+        T, B, C, H, W = _dims5(x)
+        if sum(widths) != C:
+            raise RuntimeError(f"split_channels: widths {widths} do not add up to {C} channels")
+        ctx.widths, ctx.like = tuple(widths), (T, B, H, W)
+        ld, outs, off = cl_stride(x), [], 0
+        for c in widths:
+            t = _alias(x, x.storage_offset() + off, T, B, c, H, W, ld)
+            t._snn_grad_in_slot = True
+            outs.append(t)
+            off += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        T, B, H, W = ctx.like
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        gs = [None if g is None else _raw_to_cl(g) for g in gs]
+        first = gs[0]
+        joined = first is not None
+        if joined:
+            ld, base, off = cl_stride(first), first.untyped_storage().data_ptr(), first.storage_offset()
+            for g, c in zip(gs, ctx.widths):
+                if (g is None or g.untyped_storage().data_ptr() != base or g.storage_offset() != off or cl_stride(g) != ld
+                        or g.dtype != first.dtype or tuple(g.shape) != (T, B, c, H, W)):
+                    joined = False
+                    break
+                off += c
+        if joined:
+            return _alias(first, first.storage_offset(), T, B, sum(ctx.widths), H, W, ld), None
+        like = live[0]
+        out = _new_cl((T, B), sum(ctx.widths), H, W, like)
+        off = 0
+        for g, c in zip(gs, ctx.widths):
+            dst = out.narrow(2, off, c)
+            if g is None:
+                dst.zero_()
+            else:
+                _copy_cl(g, dst)
+            off += c
+        return out, None
+
+
+def split_channels(x: torch.Tensor, widths: Sequence[int]) -> List[torch.Tensor]:
+    return list(_SplitChannels.apply(x, tuple(int(c) for c in widths)))
+
+
+class _SiblingConv1x1(Function):
+    """Several plain 1x1 convolutions of ONE input as one convolution with the row-stacked weight - the two
+    ``Conv(c/2, 1)`` that open the branches of a C2f block (``models/tiny_yolo.py:84-85``), whose outputs sit side by side
+    in the block's Dense merge - optionally each composed with a shared 1x1 convolution in front (``w1``: the C2f entry
+    ``Conv(c, 1)``, see ``_ComposedConv1x1``).  The input is read once instead of once per branch; backward is ONE data
+    gradient (instead of two chained through an addend: one read and one write of dx less) and ONE pixel reduction
+    ``G = sum gy x^T`` whose row blocks give the branches' weight gradients (``dw2_b = G_b w1^T``, ``dw1 = sum_b w2_b^T G_b``).
+    Arithmetic per output element is that of the separate convolutions (the same k-ordered products); only ``dw1`` sums its
+    branch contributions in another order."""
+
+    @staticmethod
+    def forward(ctx, x, w1, dest, acc, prec, slot1, slots2, *w2s):
+        _require_device(x, "conv2d input", bf16_ok=True)
+        fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
+        if x.dtype == _BF16:
+            fwd_prec = bwd_prec = _hip.PREC_BF16S
+        T, B, Cin, H, W = _dims5(x)
+        C1 = w1.shape[0] if w1 is not None else Cin
+        widths = [int(w.shape[0]) for w in w2s]
+        Ct = sum(widths)
+        for w in w2s:
+            if w.shape[1] != C1 or tuple(w.shape[2:]) != (1, 1):
+                raise RuntimeError("sibling 1x1 convolutions: weight shapes do not match the input")
+        if w1 is not None and (w1.shape[1] != Cin or tuple(w1.shape[2:]) != (1, 1)):
+            raise RuntimeError("sibling 1x1 convolutions: the composed weight does not chain")
+        x = _raw_to_cl(x)
+        w1m = None if w1 is None else w1.detach().reshape(C1, Cin).contiguous()
+        w2ms = [w.detach().reshape(c, C1).contiguous() for w, c in zip(w2s, widths)]
+        # FlatTrainer builds the stacked (composed) weight and its transpose once per optimiser step, in its batched GEMM
+        # launch; the group registers itself here on first use (w2s[0]._snn_sibling_group)
+        need_t = ctx.needs_input_grad[0]
+        cached = getattr(w2s[0], "_snn_sibling_weight", None)
+        versions = tuple(w._version for w in w2s) + ((w1._version,) if w1 is not None else ())
+        if (cached is not None and cached[0] is w1 and len(cached[1]) == len(w2s)
+                and all(a is b for a, b in zip(cached[1], w2s)) and cached[2] == versions
+                and tuple(cached[3].shape) == (Ct, Cin)):
+            wc, wct = cached[3], cached[4]
+        else:
+            if w1 is not None and all(getattr(w, "_snn_wt", None) is not None for w in (w1, *w2s)):
+                w2s[0]._snn_sibling_group = (w1, tuple(w2s))
+            wc = torch.empty((Ct, Cin), device=x.device, dtype=_F32)
+            wct = torch.empty((Cin, Ct), device=x.device, dtype=_F32) if need_t else None
+            row = 0
+            for w2m, c in zip(w2ms, widths):
+                if w1m is not None:
+                    _small_gemm(w2m, False, w1m, False, wc[row:row + c], 0, ct=wct, ct_col=row)
+                else:
+                    wc[row:row + c].copy_(w2m)
+                row += c
+            if w1m is None and need_t:
+                wct.copy_(wc.t())
+        y = _out_tensor(dest, T, B, Ct, H, W, x)
+        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), None, y.data_ptr(), cl_stride(y), T * B,
+                  H, W, Cin, H, W, Ct, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
+        ctx.prec = bwd_prec
+        ctx.save_for_backward(x, w1m, *w2ms)
+        ctx.wct = wct
+        ctx.geom = (T, B, Cin, H, W, Ct, 1, 1, H, W, 1, 0)
+        ctx.widths, ctx.c1 = widths, C1
+        ctx.slot1, ctx.slots2 = slot1, slots2
+        ctx.acc = acc
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1m, *w2ms = ctx.saved_tensors
+        T, B, Cin, H, W, Ct = ctx.geom[:6]
+        C1, widths = ctx.c1, ctx.widths
+        composed = w1m is not None
+        gy = _raw_to_cl(gy)
+        ldg, ldx = cl_stride(gy), cl_stride(x)
+        st = _stream()
+        dx = dw1 = None
+        dw2s = [None] * len(widths)
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad_accumulate(ctx.acc, gy, ldg, ctx.wct, x, ctx.geom, st, ctx.prec)
+        if any(ctx.needs_input_grad[7:]) or (composed and ctx.needs_input_grad[1]):
+            slot1, slots2 = ctx.slot1, ctx.slots2
+            slotted = all(s_ is not None for s_ in slots2) and (slot1 is not None or not composed)
+            splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, H, W, Ct, 1, 1, 1, 0, ctx.prec)
+            side_ok = slotted and USE_WGRAD_STREAM
+            main = torch.cuda.current_stream()
+            stream = _side_stream(x.device) if side_ok else main
+            if side_ok:
+                _side_retire(main, WGRAD_SIDE_DEPTH)
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                ws = torch.empty((splitk, Ct * Cin), device=x.device, dtype=_F32)
+                G = torch.empty((Ct, Cin), device=x.device, dtype=_F32)
+                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
+                          W, Ct, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, ctx.prec, stream.cuda_stream)
+                g1 = None
+                if composed:
+                    g1 = slot1.buf.view(C1, Cin) if slotted else torch.empty((C1, Cin), device=x.device, dtype=_F32)
+                    acc1 = slot1.claim() if slotted else 0
+                row = 0
+                for b, (w2m, c) in enumerate(zip(w2ms, widths)):
+                    Gb = G[row:row + c]
+                    row += c
+                    if slotted:
+                        g2, acc2 = slots2[b].buf.view(c, C1), slots2[b].claim()
+                    else:
+                        g2, acc2 = torch.empty((c, C1), device=x.device, dtype=_F32), 0
+                    if composed:
+                        _small_gemm(Gb, False, w1m, True, g2, acc2)      # dw2_b = G_b w1^T
+                        _small_gemm(w2m, True, Gb, False, g1, acc1)      # dw1 (+)= w2_b^T G_b
+                        acc1 = 1
+                    elif acc2:
+                        g2.add_(Gb)
+                    else:
+                        g2.copy_(Gb)
+                    if not slotted:
+                        dw2s[b] = g2.view(c, C1, 1, 1)
+                if composed and not slotted:
+                    dw1 = g1.view(C1, Cin, 1, 1)
+            if side_ok:
+                _side_hold(stream, x, gy)
+        return (dx, dw1, None, None, None, None, None, *dw2s)
+
+
+def sibling_conv1x1(x: torch.Tensor, w1: Optional[torch.Tensor], w2s: Sequence[torch.Tensor], dest: Optional[Dest] = None,
+                    forward_precision: Optional[str] = None, backward_precision: Optional[str] = None) -> torch.Tensor:
+    """``cat([conv1x1(h, w) for w in w2s], channels)`` with ``h = conv1x1(x, w1)`` (``h = x`` when ``w1`` is None), as one
+    convolution; ``x`` is a sequence ``[T,B,C,H,W]``."""
+    return _SiblingConv1x1.apply(x, w1, dest, _acc_of(x), _prec_codes(forward_precision, backward_precision),
+                                 _slot_of(w1), tuple(_slot_of(w) for w in w2s), *w2s)
 
 
 class BnPartial(NamedTuple):
@@ -1395,7 +1597,9 @@ class _ConcatAssemble(Function):
         for k, c in enumerate(ctx.widths):
             gk = g.narrow(2, off, c) if ctx.needs_input_grad[k + 1] else None
             if gk is not None and ctx.accs[k] is not None:
-                ctx.accs[k][0].deposit(ctx.accs[k][1], gk)
+                # a channel range of g that only branch k is handed: whoever accumulates that branch's gradient may
+                # write the total over it
+                ctx.accs[k][0].deposit(ctx.accs[k][1], gk, exclusive=True)
             grads.append(gk)
             off += c
         return tuple(grads)
@@ -1437,6 +1641,7 @@ class _Fanout(Function):
     def forward(ctx, x, n: int):
         ctx.acc = GradAccumulator()
         ctx.outer = ctx.acc.outer = _acc_of(x)
+        ctx.acc.grad_in_slot = bool(getattr(x, "_snn_grad_in_slot", False))
         outs = []
         for k in range(n):
             t = torch.empty(0, device=x.device, dtype=x.dtype)
@@ -1482,6 +1687,7 @@ class _Fanout(Function):
                 total = out[0] if single else out
         acc.deposits.clear()
         acc.fused.clear()
+        acc.exclusive.clear()
         acc.result = None
         if ctx.outer is not None:
             ctx.outer[0].deposit(ctx.outer[1], total)

@@ -110,6 +110,7 @@ class BlockGen(nn.Module):
                 if len(branch) == 1 and isinstance(branch[0], nn.Identity):
                     self._pass_offset = self._offsets[k]
                     break
+        self._siblings = self._plan_siblings()
 
     # ------------------------------------------------------------------ construction
     def _make_branch(self, in_channels: int, cfg: ListGen, unbounded: bool = False):
@@ -179,6 +180,60 @@ class BlockGen(nn.Module):
                 idx += 1
         return plan
 
+    def _plan_siblings(self):
+        """Dense block whose branches ALL open with a plain 1x1 convolution of the block input, and whose outputs land
+        side by side in the concat buffer (the C2f split ``Dense([[Conv(c/2,1), rec_block], [Conv(c/2,1)]])``,
+        ``models/tiny_yolo.py:84-85``: the first output goes to the pass-through slot at the END of the nested block's
+        slice, the second right behind it): the convolutions run as ONE (``functional.sibling_conv1x1``).
+        -> per branch ``(channel offset in this block's buffer, channels, index of the nested block or None)`` or None."""
+        if self.merge != "dense" or len(self.net) < 2 or not HF.USE_SIBLING_FUSION:
+            return None
+        specs = []
+        precs = set()
+        for b, (branch, plan) in enumerate(zip(self.net, self._plan)):
+            if not plan or plan[0] != ("layer", 0, 1) or not _is_plain_1x1(branch[0]):
+                return None
+            conv = branch[0]
+            precs.add((conv.forward_precision, conv.backward_precision))
+            if len(plan) == 1:
+                specs.append((self._offsets[b], conv.out_channels, None))
+            elif (len(plan) == 2 and plan[1][0] == "layer" and isinstance(branch[plan[1][1]], BlockGen)
+                  and branch[plan[1][1]]._pass_offset is not None and branch[plan[1][1]].in_channels == conv.out_channels):
+                nxt = branch[plan[1][1]]
+                specs.append((self._offsets[b] + nxt._pass_offset, conv.out_channels, plan[1][1]))
+            else:
+                return None
+        if len(precs) != 1:
+            return None
+        for (off, c, _), (nxt_off, _, _) in zip(specs, specs[1:]):
+            if off + c != nxt_off:
+                return None
+        return specs
+
+    def _run_siblings(self, X: torch.Tensor, promise, pre_conv):
+        """The branch-opening convolutions as one launch: -> (branch inputs, promises of the nested blocks)."""
+        specs = self._siblings
+        convs = [branch[0] for branch in self.net]
+        pendings = []
+        for b, (_, _, nested) in enumerate(specs):
+            if nested is None:
+                pendings.append(None)
+            else:
+                nxt = self.net[b][nested]
+                pendings.append(HF.ConcatPromise(nxt.out_channels,
+                                                 parent=HF.Dest(promise, self._offsets[b], self._branch_channels[b])))
+        first = convs[0]
+        fp = (pre_conv.forward_precision if pre_conv is not None else None) or first.forward_precision
+        bp = (pre_conv.backward_precision if pre_conv is not None else None) or first.backward_precision
+        dest = HF.Dest(promise, specs[0][0], sum(c for _, c, _ in specs))
+        whole = HF.sibling_conv1x1(X, pre_conv.weight if pre_conv is not None else None, [c.weight for c in convs],
+                                   dest=dest, forward_precision=fp, backward_precision=bp)
+        T, B, _, H, W = whole.shape
+        for p in pendings:
+            if p is not None:
+                p.get(T, B, H, W, whole)   # the nested block's buffer = its slice of this block's, now holding its pass slot
+        return HF.split_channels(whole, [c for _, c, _ in specs]), pendings
+
     def _opens_with_1x1(self, in_channels: int) -> bool:
         """Every branch starts with a plain 1x1 convolution of the block input (and nothing else reads it)."""
         if self.in_channels != in_channels or not len(self.net):
@@ -209,7 +264,12 @@ class BlockGen(nn.Module):
             dest = promise = None
         if self.merge == "dense" and zero_copy and promise is None:
             promise = HF.ConcatPromise(self.out_channels, parent=dest)
-        inputs = HF.fanout(X, len(self.net))
+        siblings = None
+        if (self._siblings is not None and zero_copy and HF.USE_SIBLING_FUSION and X.is_cuda
+                and (X.dtype != torch.bfloat16 or all(c % 32 == 0 for c in (self.in_channels, *(s[1] for s in self._siblings))))):
+            inputs, siblings = self._run_siblings(X, promise, pre_conv)
+        else:
+            inputs = HF.fanout(X, len(self.net))
         for b, (branch, flags, plan, branch_state) in enumerate(zip(self.net, self.branch_state, self._plan, state)):
             branch_state = [None] * len(branch) if branch_state is None else branch_state
             if self.merge == "dense":
@@ -221,7 +281,11 @@ class BlockGen(nn.Module):
             fuse_here = self._fused_shortcut is not None and self._fused_shortcut[0] == b
             Y = inputs[b]
             pending = None  # promise prepared for the next step (a Dense block with a Pass branch)
+            if siblings is not None:
+                pending = siblings[b]   # (the fused convolution was step 0 of every branch)
             for k, (kind, idx, span) in enumerate(plan):
+                if siblings is not None and k == 0:
+                    continue
                 last = k == len(plan) - 1
                 step_dest = branch_dest if last else None
                 step_promise, pending = pending, None

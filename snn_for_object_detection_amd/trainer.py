@@ -96,7 +96,7 @@ class FlatTrainer:
                 raise RuntimeError("FlatTrainer: float32 parameters only")
             # an earlier trainer's cached images must not outlive it on the parameter (they would pass the version check)
             for name in ("_snn_wt", "_snn_w16", "_snn_wt16", "_snn_wfrag", "_snn_wtfrag", "_snn_grad_slot", "_snn_composed",
-                         "_snn_compose_with"):
+                         "_snn_compose_with", "_snn_sibling_group", "_snn_sibling_weight"):
                 if hasattr(p, name):
                     delattr(p, name)
             p._snn_wt_version = -1
@@ -294,33 +294,53 @@ class FlatTrainer:
 
     def _refresh_composed(self, st: int) -> None:
         """w2 w1 (and its transpose) of every composed 1x1 pair that registered itself during a forward pass
-        (``functional._ComposedConv1x1``: ``w2._snn_compose_with = w1``), all pairs in ONE launch."""
+        (``functional._ComposedConv1x1``: ``w2._snn_compose_with = w1``) and the row-stacked ``[w2a; w2b] w1`` of every
+        sibling group (``functional._SiblingConv1x1``: ``w2a._snn_sibling_group = (w1, (w2a, w2b))``), all products in
+        ONE launch."""
+        def plain_1x1(*ws):
+            return all(id(w) in self._offset_of and w.dim() == 4 and tuple(w.shape[2:]) == (1, 1) for w in ws)
+
         pairs = [(p._snn_compose_with, p) for p in self._conv_params if getattr(p, "_snn_compose_with", None) is not None]
-        pairs = [(w1, w2) for w1, w2 in pairs if id(w1) in self._offset_of and tuple(w1.shape[2:]) == (1, 1)
-                 and tuple(w2.shape[2:]) == (1, 1) and w2.shape[1] == w1.shape[0]]
-        if not pairs:
+        pairs = [(w1, w2) for w1, w2 in pairs if plain_1x1(w1, w2) and w2.shape[1] == w1.shape[0]]
+        groups = [p._snn_sibling_group for p in self._conv_params if getattr(p, "_snn_sibling_group", None) is not None]
+        groups = [(w1, w2s) for w1, w2s in groups if plain_1x1(w1, *w2s) and all(w.shape[1] == w1.shape[0] for w in w2s)]
+        if not pairs and not groups:
             return
-        key = tuple((id(w1), id(w2)) for w1, w2 in pairs)
+        key = (tuple((id(w1), id(w2)) for w1, w2 in pairs), tuple((id(w1), tuple(id(w) for w in w2s)) for w1, w2s in groups))
         if getattr(self, "_composed_key", None) != key:
-            rows, off = [], 0
-            for w1, w2 in pairs:
+            rows, views, off = [], [], 0
+            for w1, w2 in pairs:                       # {A = w2, B = w1, C, Ct, M, N, K, ldct}
                 c2, c1, cin = w2.shape[0], w1.shape[0], w1.shape[1]
-                rows.append([self._offset_of[id(w2)], self._offset_of[id(w1)], off, off, c2, cin, c1])   # A = w2, B = w1
+                rows.append([self._offset_of[id(w2)], self._offset_of[id(w1)], off, off, c2, cin, c1, 0])
+                views.append(("pair", w1, w2, off, c2, cin))
                 off += (c2 * cin + 3) // 4 * 4
+            for w1, w2s in groups:                     # row blocks of ONE [sum c2][cin] matrix, column blocks of its transpose
+                c1, cin = w1.shape[0], w1.shape[1]
+                ct = sum(w.shape[0] for w in w2s)
+                row0 = 0
+                for w in w2s:
+                    rows.append([self._offset_of[id(w)], self._offset_of[id(w1)], off + row0 * cin, off + row0, w.shape[0],
+                                 cin, c1, ct])
+                    row0 += w.shape[0]
+                views.append(("group", w1, w2s, off, ct, cin))
+                off += (ct * cin + 3) // 4 * 4
             dev = self.flat_param.device
             self._composed_table = torch.tensor(rows, dtype=torch.int64, device=dev)
             self._composed_c = torch.empty(off, device=dev, dtype=torch.float32)
             self._composed_ct = torch.empty(off, device=dev, dtype=torch.float32)
             self._composed_tiles = max(((r[4] + 31) // 32) * ((r[5] + 31) // 32) for r in rows)
-            self._composed_rows = rows
+            self._composed_views = views
             self._composed_key = key
         _hip.call("snn_small_gemm_batched", self.flat_param.data_ptr(), self.flat_param.data_ptr(),
-                  self._composed_c.data_ptr(), self._composed_ct.data_ptr(), self._composed_table.data_ptr(), len(pairs),
-                  self._composed_tiles, st)
-        for (w1, w2), r in zip(pairs, self._composed_rows):
-            c2, cin = r[4], r[5]
-            w2._snn_composed = (w1, (w1._version, w2._version), self._composed_c[r[2]:r[2] + c2 * cin].view(c2, cin),
-                                self._composed_ct[r[2]:r[2] + c2 * cin].view(cin, c2))
+                  self._composed_c.data_ptr(), self._composed_ct.data_ptr(), self._composed_table.data_ptr(),
+                  int(self._composed_table.shape[0]), self._composed_tiles, st)
+        for kind, w1, w2, off, rows_c, cin in self._composed_views:
+            c = self._composed_c[off:off + rows_c * cin].view(rows_c, cin)
+            ct = self._composed_ct[off:off + rows_c * cin].view(cin, rows_c)
+            if kind == "pair":
+                w2._snn_composed = (w1, (w1._version, w2._version), c, ct)
+            else:
+                w2[0]._snn_sibling_weight = (w1, w2, tuple(w._version for w in w2) + (w1._version,), c, ct)
 
     # ------------------------------------------------------------------
     def zero_grad(self) -> None:

@@ -164,8 +164,10 @@ def test_layer_major_equals_time_outer_on_device(S):
     loss_b = (cls_b.square().mean() + box_b.square().mean())
     grads_b = torch.autograd.grad(loss_b, [p for p in model.parameters() if p.requires_grad])
     assert torch.equal(cls_a, cls_b) and torch.equal(box_a, box_b)
+    # gradients: the sequence path runs the C2f sibling convolutions as ONE data gradient over the stacked channels, the
+    # single-step path as two chained ones - the same bf16 x 3 products (1e-5 relative each) summed in another order
     for ga, gb in zip(grads_a, grads_b):
-        assert rel_err(ga, gb) < 1e-5
+        assert rel_err(ga, gb) < 5e-5
 
 
 def test_predict_streaming_matches_oracle(S):
