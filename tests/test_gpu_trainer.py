@@ -381,10 +381,11 @@ def test_event_frame_layer_forms_dy_inside_its_weight_gradient(S):
 
 
 def test_composed_1x1_weights_come_from_one_batched_launch_per_step(S):
-    """The C2f entry pairs (models/tiny_yolo.py:76-82) register themselves during the first forward pass; from the next
-    optimiser step on FlatTrainer composes w2 w1 (and its transpose) for ALL of them in one launch
-    (snn_small_gemm_batched) and the forward pass issues no composition GEMM any more - with the same bits as the per-call
-    product, and with a stale cache (weights changed behind the trainer's back) never used."""
+    """The C2f entry groups (models/tiny_yolo.py:76-85: Conv(c,1) composed with the two branch-opening Conv(c/2,1), run as
+    one convolution with the row-stacked weight) register themselves during the first forward pass; from the next optimiser
+    step on FlatTrainer composes [w2a; w2b] w1 (and its transpose) for ALL of them in one launch (snn_small_gemm_batched)
+    and the forward pass issues no composition GEMM any more - with the same bits as the per-call products, and with a
+    stale cache (weights changed behind the trainer's back) never used."""
     from snn_for_object_detection_amd import _hip
     from snn_for_object_detection_amd.trainer import FlatTrainer
     T, B, H, W = 3, 2, 32, 48
@@ -412,8 +413,8 @@ def test_composed_1x1_weights_come_from_one_batched_launch_per_step(S):
 
     run()                                   # registers the pairs
     tr.step()                               # update + refresh: composes them in one launch
-    pairs = [p for p in model.parameters() if getattr(p, "_snn_composed", None) is not None]
-    assert len(pairs) >= 5
+    pairs = [p for p in model.parameters() if getattr(p, "_snn_sibling_weight", None) is not None]
+    assert len(pairs) == 5                  # one group per C2f block
     _hip.PROFILER = cnt = Count()
     try:
         loss_cached, grad_cached = run()
@@ -421,13 +422,13 @@ def test_composed_1x1_weights_come_from_one_batched_launch_per_step(S):
         _hip.PROFILER = None
     n_gemm_cached = cnt.names.count("snn_small_gemm")
     for p in pairs:
-        del p._snn_composed                 # the per-call composition again
+        del p._snn_sibling_weight           # the per-call composition again
     _hip.PROFILER = cnt2 = Count()
     try:
         loss_call, grad_call = run()
     finally:
         _hip.PROFILER = None
-    assert cnt2.names.count("snn_small_gemm") == n_gemm_cached + len(pairs)     # one forward GEMM per pair came back
+    assert cnt2.names.count("snn_small_gemm") == n_gemm_cached + 2 * len(pairs)   # one forward GEMM per branch came back
     assert torch.equal(loss_cached, loss_call) and torch.equal(grad_cached, grad_call)
     # a weight changed behind the trainer (version counter moved): the cached product is not used
     tr.step()
@@ -438,7 +439,7 @@ def test_composed_1x1_weights_come_from_one_batched_launch_per_step(S):
         run()
     finally:
         _hip.PROFILER = None
-    assert cnt3.names.count("snn_small_gemm") == n_gemm_cached + 1
+    assert cnt3.names.count("snn_small_gemm") == n_gemm_cached + 2
 
 
 @pytest.mark.gpu
