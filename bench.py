@@ -536,12 +536,12 @@ def main():
         from snn_for_object_detection_amd import functional as HF
         prof = KernelProfiler() if rank == 0 else None
         _hip.PROFILER = prof
-        side_stream_was = HF.USE_WGRAD_STREAM
-        HF.USE_WGRAD_STREAM = False
+        side_stream_was, head_streams_was = HF.USE_WGRAD_STREAM, HF.USE_HEAD_STREAMS
+        HF.USE_WGRAD_STREAM = HF.USE_HEAD_STREAMS = False
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        HF.USE_WGRAD_STREAM = side_stream_was
+        HF.USE_WGRAD_STREAM, HF.USE_HEAD_STREAMS = side_stream_was, head_streams_was
         _hip.PROFILER = None
     if rank == 0 and not args.no_roofline:
         table = prof.summary()
@@ -569,7 +569,8 @@ def main():
                  "bound": roofline_head(k, r, args.forward_precision, args.backward_precision, sb)["bound"]}
                 for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if r["ms"] / total_ms >= 0.02]
                 + [c for c in [chain_row(table, prof.neuron_steps, 2, sb)] if c],
-            "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream off",
+            "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream and head "
+                      "streams off (every kernel alone on the GPU)",
         }
         if args.kernel_table:
             for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):

@@ -190,6 +190,47 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# Independent sub-networks (the detection heads behind the ``Return`` taps, generator.Head) CAN run on auxiliary streams
+# beside the main stream: the 30x38 head then overlaps the latency-bound 15x19 / 8x10 neck stages, forward and - because
+# autograd runs a node's backward on the stream of its forward - backward.  Built, bit-identical (tests/test_gpu_model.py)
+# and measured in round 4: NOT faster - same-call A/B, three rounds: 23.37 / 23.15 / 23.24 ms with one head stream
+# against 23.11 / 23.01 / 22.95 without, 22.97 with two (tools/ab.sh): what runs beside a kernel that fills the CUs only
+# takes its share of them, and the cross-stream events cost more than the launch tails they fill.  So: OFF unless
+# SNN_HEAD_STREAMS=<n> asks for n streams.
+HEAD_STREAMS = int(os.environ.get("SNN_HEAD_STREAMS", "0") or 0)   # heads (largest maps first) with a stream of their own
+USE_HEAD_STREAMS = HEAD_STREAMS > 0
+_AUX_STREAMS = {}   # device -> [streams], probed like the weight-gradient stream
+_AUX_HOME = {}      # device -> the stream the auxiliary streams run beside (the "main" stream of the step)
+
+
+def aux_streams(device, n: int) -> List["torch.cuda.Stream"]:
+    """``n`` streams that really run beside the current stream (and beside the weight-gradient stream)."""
+    have = _AUX_STREAMS.setdefault(device, [])
+    if len(have) < n:
+        main = torch.cuda.current_stream(device)
+        _AUX_HOME[device] = main
+        while len(have) < n:
+            have.append(concurrent_stream(main, avoid=tuple(_SIDE_STREAMS.values()) + tuple(have)))
+    return have[:n]
+
+
+def on_aux_stream(device=None) -> bool:
+    """True while the current stream is one of the auxiliary streams (weight gradients then run inline on it: the
+    side-stream bookkeeping below assumes ONE main stream)."""
+    cur = torch.cuda.current_stream(device)
+    return any(cur.cuda_stream == s.cuda_stream for ss in _AUX_STREAMS.values() for s in ss)
+
+
+def aux_streams_sync() -> None:
+    """Make the current stream wait for everything queued on the auxiliary streams (weight gradients of the heads are
+    written there; autograd joins only the streams of gradient-accumulation leaves)."""
+    for dev, ss in _AUX_STREAMS.items():
+        cur = torch.cuda.current_stream(dev)
+        for s in ss:
+            if s.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(s)
+
+
 # Operands of a side-stream kernel are kept alive HERE until the main stream has waited for that kernel, instead of
 # being handed to ``Tensor.record_stream``: a record_stream'ed block returns to the caching allocator only once the
 # GPU has really passed the event, and the host enqueues a whole backward pass ahead of the GPU - so every dy of the
@@ -214,10 +255,16 @@ def _side_hold(side, *tensors) -> None:
 
 
 def wgrad_stream_sync() -> None:
-    """Make the current stream wait for every weight-gradient kernel queued on the side stream."""
+    """Make the current stream wait for every weight-gradient kernel queued on the side stream (and on the auxiliary
+    streams of the detection heads)."""
     _SIDE_PENDING.clear()
     for dev, st in _SIDE_STREAMS.items():
         torch.cuda.current_stream(dev).wait_stream(st)
+    aux_streams_sync()
+
+
+def _wgrad_on_side() -> bool:
+    return USE_WGRAD_STREAM and not (_AUX_STREAMS and on_aux_stream())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -475,9 +522,12 @@ class GradAccumulator:
     convolution that runs for the fanned-out tensor add the gradients other branches have already produced
     in its epilogue (``snn_conv2d_dgrad(addend=...)``) instead of a separate add pass afterwards."""
 
-    __slots__ = ("deposits", "result", "fused", "outer", "exclusive", "grad_in_slot")
+    __slots__ = ("deposits", "result", "fused", "outer", "exclusive", "grad_in_slot", "marks")
 
     def __init__(self):
+        self.marks = {}       # key (or "result") -> (stream, event): where and when that tensor was produced - consulted
+        #                       only while auxiliary streams exist (the consumers of a Return tap run on different streams,
+        #                       and these tensors travel behind autograd's back)
         self.deposits = {}    # alias index -> gradient produced for that alias by a pass-through consumer
         self.result = None    # dx written by the fusing convolution
         self.fused = {}       # alias index -> deposit that went into ``result``
@@ -492,6 +542,32 @@ class GradAccumulator:
             self.deposits[key] = g
             if exclusive:
                 self.exclusive.add(key)
+            if _AUX_STREAMS:
+                self.marks[key] = _stream_mark()
+
+    def set_result(self, dx: torch.Tensor) -> None:
+        self.result = dx
+        if _AUX_STREAMS:
+            self.marks["result"] = _stream_mark()
+
+
+def _stream_mark():
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    return cur, ev
+
+
+def _await_mark(acc: "GradAccumulator", key, t: Optional[torch.Tensor]) -> None:
+    """The current stream waits for the producer of a tensor handed over through a GradAccumulator on another stream."""
+    mark = acc.marks.get(key) if _AUX_STREAMS else None
+    if mark is None:
+        return
+    cur = torch.cuda.current_stream()
+    if mark[0].cuda_stream != cur.cuda_stream:
+        cur.wait_event(mark[1])
+        if t is not None:
+            t.record_stream(cur)   # allocated on the producer's stream, read by a kernel of this one
 
 
 def _acc_of(x):
@@ -517,6 +593,7 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
     if acc is not None and acc[0].result is None and acc[0].deposits:
         # another branch of the block already produced its gradient for this tensor: add it here
         key, other = next(iter(acc[0].deposits.items()))
+        _await_mark(acc[0], key, other)
         other = _raw_to_cl(other)
         if tuple(other.shape) == dx_shape:
             addend, ld_add = other.data_ptr(), cl_stride(other)
@@ -528,6 +605,7 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
         o_acc, o_key = acc[0].outer
         if o_acc.result is None and len(o_acc.deposits) == 1 and o_key not in o_acc.deposits:
             key2, other2 = next(iter(o_acc.deposits.items()))
+            _await_mark(o_acc, key2, other2)
             other2 = _raw_to_cl(other2)
             if tuple(other2.shape) == dx_shape:
                 addend2, ld_add2 = other2.data_ptr(), cl_stride(other2)
@@ -544,6 +622,7 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
         # a sibling convolution already produced (its gradient + the fused deposits) for this tensor: add
         # that here and become the accumulated result (two convolutions on one input: the C2f split)
         prev = acc[0].result
+        _await_mark(acc[0], "result", prev)
         addend, ld_add = prev.data_ptr(), cl_stride(prev)
         chained = True
     if dx is None:
@@ -574,15 +653,15 @@ def _dgrad_accumulate(acc, gy, ldg, wt, x, geom, st, prec, wt_split=None, wt_ima
                   Cin, Ho, Wo, Cout, KH, KW, stride, pad, addend, ld_add, addend2, ld_add2, prec, st)
     if acc is not None and (acc[0].result is None or chained):
         if chained and acc[0].outer is not None and acc[0].outer[0].result is acc[0].result:
-            acc[0].outer[0].result = dx                    # the enclosing fanout expects what this
+            acc[0].outer[0].set_result(dx)                 # the enclosing fanout expects what this
             acc[0].outer[0].fused[acc[0].outer[1]] = dx    # fanout will hand back: the new total
-        acc[0].result = dx
+        acc[0].set_result(dx)
         acc[0].fused[acc[1]] = dx
     if outer_fused is not None:
         o_acc, o_key, key2 = outer_fused
         o_acc.fused[key2] = o_acc.deposits.pop(key2)
         o_acc.fused[o_key] = dx   # what the inner fanout will hand back for this alias
-        o_acc.result = dx
+        o_acc.set_result(dx)
     return dx
 
 
@@ -737,8 +816,9 @@ class _Conv2d(Function):
                 # dy is formed while the weight-gradient kernel reads gx and y: no apply pass, no dy tensor
                 splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
                 main = torch.cuda.current_stream()
-                stream = _side_stream(x.device) if USE_WGRAD_STREAM else main
-                if USE_WGRAD_STREAM:
+                on_side = _wgrad_on_side()
+                stream = _side_stream(x.device) if on_side else main
+                if on_side:
                     _side_retire(main, WGRAD_SIDE_DEPTH)
                     stream.wait_stream(main)
                 with torch.cuda.stream(stream):
@@ -746,7 +826,7 @@ class _Conv2d(Function):
                     _hip.call("snn_conv2d_wgrad_bn", x.data_ptr(), ldx, pend.gx.data_ptr(), Cout, pend.y.data_ptr(),
                               cl_stride(pend.y), pend.coef.data_ptr(), T, B, ctx.slot.buf.data_ptr(), T * B, H, W, Cin, Ho,
                               Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, stream.cuda_stream)
-                if USE_WGRAD_STREAM:
+                if on_side:
                     _side_hold(stream, x, pend.gx, pend.y, pend.coef)
                 return None, None, None, None, None, None, None, None, None
             fused_dgrad = (ctx.needs_input_grad[0] and ctx.prec == _hip.PREC_BF16X3 and USE_HALO_CONV
@@ -778,7 +858,7 @@ class _Conv2d(Function):
                 dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
-            if ctx.slot is not None and USE_WGRAD_STREAM:
+            if ctx.slot is not None and _wgrad_on_side():
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
@@ -883,7 +963,7 @@ class _ComposedConv1x1(Function):
             slot1, slot2 = ctx.slots
             slotted = slot1 is not None and slot2 is not None
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, H, W, C2, 1, 1, 1, 0, ctx.prec)
-            side_ok = slotted and USE_WGRAD_STREAM
+            side_ok = slotted and _wgrad_on_side()
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main
             if side_ok:
@@ -1059,7 +1139,7 @@ class _SiblingConv1x1(Function):
             slot1, slots2 = ctx.slot1, ctx.slots2
             slotted = all(s_ is not None for s_ in slots2) and (slot1 is not None or not composed)
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, H, W, Ct, 1, 1, 1, 0, ctx.prec)
-            side_ok = slotted and USE_WGRAD_STREAM
+            side_ok = slotted and _wgrad_on_side()
             main = torch.cuda.current_stream()
             stream = _side_stream(x.device) if side_ok else main
             if side_ok:
@@ -1657,6 +1737,7 @@ class _Fanout(Function):
         if acc.result is not None:
             # a data-gradient convolution already holds (its own + the fused deposits'); add only what is missing
             total = acc.result
+            _await_mark(acc, "result", total)   # (it may have been written on another stream than this node's)
             for k, g in enumerate(gs):
                 if g is None:
                     continue
@@ -1688,6 +1769,7 @@ class _Fanout(Function):
         acc.deposits.clear()
         acc.fused.clear()
         acc.exclusive.clear()
+        acc.marks.clear()
         acc.result = None
         if ctx.outer is not None:
             ctx.outer[0].deposit(ctx.outer[1], total)

@@ -465,11 +465,33 @@ class Head(nn.Module):
         """
         state = [None] * len(X) if state is None else state
         anchors, cls_preds, bbox_preds = [], [], []
+        # The heads are independent of each other and of the neck stages behind their tap: the first HEAD_STREAMS heads (the
+        # largest maps) run on streams of their own (functional.aux_streams) that wait for THEIR tap only, so the 30x38
+        # head overlaps the latency-bound 15x19 / 8x10 neck stages - forward and, since autograd runs a node's backward
+        # on the stream of its forward, backward.  The other heads follow the end of the neck on the main stream.  (One
+        # auxiliary stream by default: HIP has four hardware queues - main, weight gradients, gradient exchange, this.)
+        streams = [None] * len(X)
+        n_aux = min(HF.HEAD_STREAMS, len(X) - 1) if HF.USE_HEAD_STREAMS else 0
+        if (n_aux > 0 and all(m.is_cuda and m.dim() == 5 for m in X[:n_aux])
+                and all(getattr(m, "_snn_ready", None) is not None for m in X[:n_aux])):
+            streams = HF.aux_streams(X[0].device, n_aux) + [None] * (len(X) - n_aux)
+        main = torch.cuda.current_stream() if X and X[0].is_cuda else None
         for idx, map in enumerate(X):
             anchors.append(getattr(self, f"anchor_gen_{idx}")(map))
-            boxes, classes, state[idx] = getattr(self, f"model_{idx}")(map, state[idx])
+            side = streams[idx]
+            if side is None:
+                boxes, classes, state[idx] = getattr(self, f"model_{idx}")(map, state[idx])
+            else:
+                side.wait_event(map._snn_ready[1])
+                with torch.cuda.stream(side):
+                    boxes, classes, state[idx] = getattr(self, f"model_{idx}")(map, state[idx])
+                for t in (boxes, classes, *_tensors_of(state[idx])):
+                    t.record_stream(main)          # allocated on the head's stream, read on the main stream afterwards
             bbox_preds.append(boxes)
             cls_preds.append(classes)
+        for side in streams:
+            if side is not None:
+                main.wait_stream(side)
         anchors = torch.cat(anchors)
         cls_preds = self._concat_preds(cls_preds)
         cls_preds = cls_preds.reshape(cls_preds.shape[0], -1, self.num_classes + 1)
@@ -518,6 +540,15 @@ class HeadGen(ModelGen):
         if box.dtype == torch.bfloat16:
             box, cls = HF.to_float32(box), HF.to_float32(cls)
         return box, cls, state
+
+
+def _tensors_of(state):
+    """Every tensor of a (nested) state list / tuple."""
+    if isinstance(state, torch.Tensor):
+        yield state
+    elif isinstance(state, (list, tuple)):
+        for s in state:
+            yield from _tensors_of(s)
 
 
 def _has_state(m: nn.Module) -> bool:

@@ -251,8 +251,8 @@ class FlatTrainer:
                                                           avoid=tuple(_HF._SIDE_STREAMS.values()))
             comm = self._comm_stream
             comm.wait_stream(torch.cuda.current_stream())
-            for st in _HF._SIDE_STREAMS.values():
-                comm.wait_stream(st)
+            for st in list(_HF._SIDE_STREAMS.values()) + [a for ss in _HF._AUX_STREAMS.values() for a in ss]:
+                comm.wait_stream(st)   # (weight gradients of the heads are written on their auxiliary streams)
             with torch.cuda.stream(comm):
                 self._early_work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self._grad_group, async_op=True)
         else:

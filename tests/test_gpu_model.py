@@ -211,3 +211,37 @@ def test_readme_style_generated_net(S):
     out_r = torch.stack(outs)
     assert out.shape == out_r.shape
     assert (out.cpu() != out_r).float().mean().item() < 1e-3
+
+
+def test_heads_on_auxiliary_streams_are_bit_identical(S):
+    """``functional.USE_HEAD_STREAMS`` (opt-in, measured not faster - DESIGN section 5): the first heads run on streams of
+    their own, forward and backward; gradient tensors that travel between consumers of a ``Return`` tap behind autograd's
+    back carry stream marks.  Same loss and gradients bit for bit, three steps in a row."""
+    from snn_for_object_detection_amd.trainer import FlatTrainer
+    HF = S.functional
+    T, B, H, W = 6, 2, 64, 96
+    X, labels = synthetic_events(T, B, H, W, p=0.1).cuda(), synthetic_labels(B).cuda()
+
+    def run(n_streams):
+        was = HF.USE_HEAD_STREAMS, HF.HEAD_STREAMS
+        HF.USE_HEAD_STREAMS, HF.HEAD_STREAMS = n_streams > 0, n_streams
+        try:
+            torch.manual_seed(3)
+            model = S.TinyYolo(num_classes=2, time_window=0).cuda().train()
+            tr = FlatTrainer(model, lr=1e-3)
+            out = []
+            for _ in range(3):
+                tr.zero_grad()
+                loss = model.training_step((X, labels))
+                loss.backward()
+                tr.synchronize()
+                out.append((loss.detach().clone(), tr.flat_grad.clone()))
+                tr.step()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            HF.USE_HEAD_STREAMS, HF.HEAD_STREAMS = was
+    plain, one, two = run(0), run(1), run(2)
+    for a, b, c in zip(plain, one, two):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
