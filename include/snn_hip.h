@@ -81,10 +81,15 @@ enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even 
                                         soda.py:141-144): fwd writes out[M][ldo] of step T-1 instead of [T][M][ldo];
                                         bwd takes g_out[M][ldg] (and, LI+Tanh, the saved output [M][C]) of that step,
                                         the output gradient of every earlier step being zero */
-       SNN_SCAN_BF16_STORAGE = 4     /* bf16-storage mode (see SNN_PREC_BF16S): the activation tensors of the call - fwd: y,
+       SNN_SCAN_BF16_STORAGE = 4,    /* bf16-storage mode (see SNN_PREC_BF16S): the activation tensors of the call - fwd: y,
                                         out, addend, vdec; bwd: g_out, state, y, gx - are bf16 (pointers passed as float*,
                                         strides in elements); state (v, i), alpha / beta and the sums stay fp32.
-                                        NONE / LIF / LI / LI+Tanh, C and strides multiples of 4 */ };
+                                        NONE / LIF / LI / LI+Tanh, C and strides multiples of 4 */
+       SNN_SCAN_SPIKES_FROM_VDEC = 8 /* fwd, Norm -> LIF without a shortcut whose potentials are saved (vdec != NULL): write
+                                        NO output tensor (out must be NULL) - the saved pre-reset potentials already hold
+                                        the spikes, z = (v_dec > v_th), and the consumer forms them while it reads them
+                                        (snn_conv1x1_spikes_fwd / _wgrad): 4 of the 12 bytes the scan moves per
+                                        neuron-timestep never exist.  fp32 tensors, C and ldy multiples of 4 */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
@@ -234,6 +239,25 @@ int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy,
  * floats); same geometry arguments as snn_conv2d_wgrad; host-only, callable without a device */
 int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                             int stride, int pad, int precision);
+/* ---- 1x1 convolutions over spikes that were never stored.  The stage-entry layers of the generated nets are
+ * Conv -> Norm -> LIF feeding only 1x1 convolutions (reference models/tiny_yolo.py:76-85 behind :16-21); their LIF
+ * (models/modules/layer_gen.py:232-235) saves v_dec for its backward pass anyway, so the spike tensor z = (v_dec > v_th)
+ * is not written (SNN_SCAN_SPIKES_FROM_VDEC) and these entry points take the POTENTIALS as their input tensor:
+ *   snn_conv1x1_spikes_fwd   : y[N][H][W][ldy] (Cout channels) = conv1x1(z, w[Cout][Cin]), fp16 x 3 arithmetic - a spike
+ *                              is exact in one fp16 piece, so two of the three products are issued; same bits as
+ *                              snn_conv2d_fwd(z, ...)
+ *   snn_conv1x1_spikes_wgrad : dw[Cout][Cin] (+)= sum_pixels dy z^T, bf16 x 3 arithmetic (two products); workspace / splitk
+ *                              as for snn_conv2d_wgrad with KH = KW = 1 (snn_conv2d_wgrad_splitk); same bits as
+ *                              snn_conv2d_wgrad(z, ...)
+ *   snn_conv1x1_spikes_supported : 1 for the shapes covered (Cin % 32 == 0, Cout % 4 == 0, ld % 4 == 0, the two default
+ *                              arithmetics); otherwise the layer must write its spikes.
+ * v_th >= 0 (padding rows read as potential 0 and must not spike).  The data gradient needs no input tensor. */
+int snn_conv1x1_spikes_supported(int64_t N, int H, int W, int Cin, int Cout, int64_t ld, int fwd_precision,
+                                 int bwd_precision);
+int snn_conv1x1_spikes_fwd(const float* vdec, int64_t ld, float v_th, const float* w, float* y, int64_t ldy, int64_t N, int H,
+                           int W, int Cin, int Cout, void* stream);
+int snn_conv1x1_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw, int64_t N,
+                             int H, int W, int Cin, int Cout, int accumulate, float* workspace, int splitk, void* stream);
 
 /* ---------------------------------------------------------------- batch-norm statistics
  * Train-mode nn.BatchNorm2d (layer_gen.py:211-214) applied per TIMESTEP: for every (t,c)

@@ -17,7 +17,7 @@ POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 9
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
-SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE = 1, 2, 4
+SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE, SCAN_SPIKES_FROM_VDEC = 1, 2, 4, 8
 
 
 class NeuronParams(Structure):
@@ -59,6 +59,9 @@ SIGNATURES = {
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P]),
     "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "snn_conv1x1_spikes_supported": (c_int, [_L, _I, _I, _I, _I, _L, _I, _I]),
+    "snn_conv1x1_spikes_fwd": (c_int, [_P, _L, _F, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
+    "snn_conv1x1_spikes_wgrad": (c_int, [_P, _L, _F, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
     "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_bn_stats_finalize": (c_int, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),

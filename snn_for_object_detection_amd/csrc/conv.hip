@@ -85,6 +85,7 @@ struct ConvGeom {
     double* bn_partial;
     int64_t bn_rows;   // output pixels per timestep (>= BM: a row tile meets at most two timesteps)
     int bn_chunks;     // chunk slots per timestep
+    float x_th;        // XSP kernels: the gathered tensor holds saved LIF potentials, the operand is z = (v_dec > x_th)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -175,7 +176,13 @@ __device__ __forceinline__ int div_magic(int n, int d, unsigned magic) { return 
 // SB (FAST, SPLIT 5 only; SNN_PREC_BF16S, the bf16-STORAGE throughput mode): `in`, `out` and the addends are bf16 tensors
 // (strides in elements).  The gathered rows arrive as 8-byte loads and go to LDS as they are - no conversion; the
 // epilogue rounds the fp32 accumulators to bf16 on their way out.  Weights stay fp32 and are rounded in the loader.
-template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false, bool SB = false>
+// XSP (FAST, forward, SPLIT 4 only; snn_conv1x1_spikes_fwd): `in` holds the pre-reset potentials v_dec a LIF layer saved for
+// its backward pass, NOT its output - that layer wrote no spike tensor at all (SNN_SCAN_SPIKES_FROM_VDEC) and the operand
+// is formed here, z = (v_dec > x_th), on the way into LDS.  A spike is exact in ONE fp16 piece (16.0 or 0 after the 2^4
+// pre-scale): no low image is written or read and the product low(x) * high(w) - identically zero - is not issued: two
+// MFMA products per multiply-add, same bits as the three-product kernel fed the stored spikes.
+template <int BN, int WM, int WN, bool DGRAD, bool VEC, int SPLIT, bool FAST, bool PRESPLIT = false, bool SB = false,
+          bool XSP = false>
 __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (DGRAD ? 4 : SNN_GATHER_SB_WAVES) : 2)) : SNN_CONV_MIN_WAVES) void k_conv_gather(const float* __restrict__ in, const float* __restrict__ wk,
                                                           float* __restrict__ out, ConvGeom g,
                                                           const float* __restrict__ addend, int64_t ld_add,
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
     constexpr int BROWS = BN / 32;  // B rows loaded per thread
     static_assert(WM * WN == 4, "4 waves");
     static_assert(!SB || (FAST && SPLIT == 5 && !PRESPLIT), "bf16 storage: the pipelined one-product kernel");
+    static_assert(!XSP || (FAST && SPLIT == 4 && !DGRAD && !PRESPLIT && !SB), "spikes from potentials: fp16 x 3 forward");
     constexpr int ES = SB ? 2 : 4;   // bytes per activation element in HBM
     constexpr int NPIECE = SPLIT == 3 ? 3 : (SPLIT == 5 ? 1 : 2);  // 16-bit images per operand
     constexpr int A_BYTES = SPLIT ? NPIECE * BM * LDB * 2 : BM * LDK * 4;
@@ -508,7 +516,13 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
         };
         auto convert_a = [&](const AReg& v, bf16x4* out) {
             if constexpr (SB) out[0] = __builtin_bit_cast(bf16x4, v);   // already the bf16 values
-            else convert(v, out, kF16ActScale);
+            else if constexpr (XSP) {   // z = (v_dec > th) as ONE fp16 piece of z * 2^4: 0x4C00 (16.0) or 0
+                u32x2 hi;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+                    hi[e >> 1] = (v[e] > g.x_th ? 0x4C00u : 0u) | (v[e + 1] > g.x_th ? 0x4C000000u : 0u);
+                out[0] = __builtin_bit_cast(bf16x4, hi);
+            } else convert(v, out, kF16ActScale);
         };
         auto convert_b = [&](const f32x4& v, bf16x4* out) {
             if constexpr (PRESPLIT) {   // the 16 bytes already are (4 hi, 4 lo)
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
             for (int j = 0; j < 4; ++j) {
                 const int o = (lr + 32 * j) * LDB + kq;
                 *reinterpret_cast<bf16x4*>(&Ah[o]) = pa[j][0];
-                if constexpr (NP >= 2) *reinterpret_cast<bf16x4*>(&Al[o]) = pa[j][1];
+                if constexpr (NP >= 2 && !XSP) *reinterpret_cast<bf16x4*>(&Al[o]) = pa[j][1];
                 if constexpr (NP >= 3) *reinterpret_cast<bf16x4*>(&Am[o]) = pa[j][2];
             }
 #pragma unroll
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
             for (int i = 0; i < TM; ++i) {
                 const int off = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + 8 * h;
                 ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[off]);
-                if constexpr (NP >= 2) al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
+                if constexpr (NP >= 2 && !XSP) al[i] = *reinterpret_cast<const bf16x8*>(&Al[off]);
                 if constexpr (NP >= 3) am[i] = *reinterpret_cast<const bf16x8*>(&Am[off]);
             }
 #pragma unroll
@@ -557,6 +571,13 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
                 for (int j = 0; j < TN; ++j) {  // small terms first
                     if constexpr (SPLIT == 5) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        continue;
+                    }
+                    if constexpr (SPLIT == 4 && XSP) {   // the low image of a spike is zero: two products
+                        const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]);
+                        const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, acc[i][j], 0, 0, 0);
                         continue;
                     }
                     if constexpr (SPLIT == 4) {
@@ -577,10 +598,10 @@ __global__ __launch_bounds__(kThreads, (FAST && SPLIT) ? (PRESPLIT ? 3 : (SB ? (
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         };
-        constexpr int NM = TM * TN * NPROD;              // MFMAs per k16 group
-        constexpr int NREAD = (TM + TN) * NP;            // ds_read_b128 per k16 group
+        constexpr int NM = TM * TN * (XSP ? 2 : NPROD);  // MFMAs per k16 group
+        constexpr int NREAD = XSP ? TM + TN * NP : (TM + TN) * NP;   // ds_read_b128 per k16 group
         constexpr int CONV_OPS = SPLIT == 3 ? 24 : (SPLIT == 5 ? 2 : 14);   // VALU per converted f32x4 (approx.)
-        constexpr int VPG_A = (4 * CONV_OPS + NM - 1) / NM;
+        constexpr int VPG_A = ((XSP ? 4 * 8 : 4 * CONV_OPS) + NM - 1) / NM;
         constexpr int VPG_B = PRESPLIT ? 1 : (BROWS * CONV_OPS + NM - 1) / NM;   // pre-split: only register moves
         if (g.Ktot > 0) {
             // both first tiles are requested back to back (the accumulators are not live yet, registers are free):
@@ -852,6 +873,7 @@ struct WgradGeom {
     int64_t pix_per_split;
     int tiles_m, tiles_n, splitk;
     int nimg;
+    float x_th;    // XSP kernels: x holds saved LIF potentials, the operand is z = (v_dec > x_th)
 };
 
 // Block tile (32*TM*WM) out-channels x (32*TN*WN) (tap,ci) columns; each wave owns TM x TN accumulators of
@@ -1053,7 +1075,10 @@ __global__ __launch_bounds__(kThreads, SNN_CONV_MIN_WAVES) void k_conv_wgrad(con
 //     issued before the barrier; between the two barriers only the LDS writes remain.
 // SB (ONE only; bf16-storage mode): x and dy are bf16 tensors - 8-byte loads, the 4 x 4 transposition to "4 pixels of a
 // channel" is bit shuffling, nothing is converted.
-template <int TM, int TN, int WM, int WN, int WBK, bool ONE, bool SB = false>   // ONE: bf16 x 1 (hi pieces only, one product)
+// XSP (bf16 x 3 only; snn_conv1x1_spikes_wgrad): x holds the saved potentials v_dec of a LIF layer that wrote no spike tensor
+// (see k_conv_gather XSP); the operand z = (v_dec > x_th) is formed in the conversion - one exact bf16 piece (0x3F80 or 0),
+// no low image, and the product high(dy) * low(x) is not issued: two MFMA products per multiply-add.
+template <int TM, int TN, int WM, int WN, int WBK, bool ONE, bool SB = false, bool XSP = false>   // ONE: bf16 x 1 (hi pieces only, one product)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ ws, WgradGeom g) {
@@ -1064,6 +1089,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     // the memory latency they have to cover (PMC: 58 % of the wave cycles parked in s_waitcnt / barriers)
     static_assert(WBK == 32 || WBK == 64, "stage length");
     static_assert(!SB || ONE, "bf16 storage: one product");
+    static_assert(!XSP || (!ONE && !SB), "spikes from potentials: the bf16 x 3 kernel");
     constexpr int ES = SB ? 2 : 4;   // bytes per activation element in HBM
     constexpr int LDW = WBK + 8;      // bf16 row pitch: 80 / 144 bytes, conflict-free ds_read_b128 fragments
     constexpr int NQ = WBK / 4;       // pixel quads per stage
@@ -1072,7 +1098,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
     __shared__ __attribute__((aligned(16))) __bf16 Dh[BMc * LDW];
     __shared__ __attribute__((aligned(16))) __bf16 Dl[ONE ? 8 : BMc * LDW];
     __shared__ __attribute__((aligned(16))) __bf16 Xh[BNk * LDW];
-    __shared__ __attribute__((aligned(16))) __bf16 Xl[ONE ? 8 : BNk * LDW];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[(ONE || XSP) ? 8 : BNk * LDW];
     __shared__ __attribute__((aligned(16))) int Pinfo[2][WBK][4];  // {byte offset of the pixel origin, y0, x0, valid}
 
     const int tid = threadIdx.x;
@@ -1227,6 +1253,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             }
         }
     };
+    auto convert_spikes = [&](const OReg (&v)[4], bf16x4 (&out)[4][2]) {   // XSP: 4 pixels of a channel as bf16 {0, 1}
+        if constexpr (XSP) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32x2 o;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+                    o[e >> 1] = (v[e][c] > g.x_th ? 0x3F80u : 0u) | (v[e + 1][c] > g.x_th ? 0x3F800000u : 0u);
+                out[c][0] = __builtin_bit_cast(bf16x4, o);
+            }
+        }
+    };
     auto write_tiles = [&]() {
 #pragma unroll
         for (int q = 0; q < DQ; ++q)
@@ -1243,7 +1281,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     *reinterpret_cast<bf16x4*>(&Xh[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][0];
-                    if constexpr (!ONE) *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][1];
+                    if constexpr (!ONE && !XSP) *reinterpret_cast<bf16x4*>(&Xl[(x_cq[q] + c) * LDW + quad * 4]) = px[q][c][1];
                 }
             }
     };
@@ -1268,7 +1306,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         for (int j = 0; j < TN; ++j) {
             const int off = ((wn * TN + j) * 32 + r) * LDW + ks * 16 + 8 * h;
             bh[j] = *reinterpret_cast<const bf16x8*>(&Xh[off]);
-            if constexpr (!ONE) bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
+            if constexpr (!ONE && !XSP) bl[j] = *reinterpret_cast<const bf16x8*>(&Xl[off]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1276,15 +1314,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
             for (int j = 0; j < TN; ++j) {
                 if constexpr (!ONE) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if constexpr (!XSP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
     };
-    constexpr int NM = TM * TN * (ONE ? 1 : 3);
-    constexpr int NREAD = (TM + TN) * (ONE ? 1 : 2);
+    constexpr int NM = TM * TN * (ONE ? 1 : (XSP ? 2 : 3));
+    constexpr int NREAD = XSP ? 2 * TM + TN : (TM + TN) * (ONE ? 1 : 2);
     constexpr int CQ_OPS = SB ? 12 : 56;   // VALU per converted quad (approx.)
-    constexpr int VPG_D = (DQ * CQ_OPS + NM - 1) / NM, VPG_X = (XQ * CQ_OPS + NM - 1) / NM;
+    constexpr int VPG_D = (DQ * CQ_OPS + NM - 1) / NM, VPG_X = (XQ * (XSP ? 24 : CQ_OPS) + NM - 1) / NM;
 
     decode(0);
     __syncthreads();
@@ -1294,7 +1332,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
 #pragma unroll
     for (int q = 0; q < DQ; ++q) convert_quad(rd[q], pd[q]);
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) convert_quad(rx[q], px[q]);
+    for (int q = 0; q < XQ; ++q) {
+        if constexpr (XSP) convert_spikes(rx[q], px[q]);
+        else convert_quad(rx[q], px[q]);
+    }
     write_tiles();
     load_tiles(p_lo + WBK, 1);
     decode(0);
@@ -1315,7 +1356,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_pipe(const float* __
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(1);
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) convert_quad(rx[q], px[q]);
+        for (int q = 0; q < XQ; ++q) {
+            if constexpr (XSP) convert_spikes(rx[q], px[q]);
+            else convert_quad(rx[q], px[q]);
+        }
         __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
@@ -1416,7 +1460,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
-template <bool DGRAD, int SPLIT, bool SB = false>
+template <bool DGRAD, int SPLIT, bool SB = false, bool XSP = false>
 static int launch_gather(const float* in, const float* wk, const void* wk_split, float* out, const ConvGeom& g,
                          const float* addend, int64_t ld_add, const float* addend2, int64_t ld_add2, hipStream_t st,
                          const char* name) {
@@ -1435,6 +1479,9 @@ static int launch_gather(const float* in, const float* wk, const void* wk_split,
     if constexpr (SB)
         SNN_REQUIRE(fast, "%s: bf16 storage covers the pipelined implicit GEMM only (channels a multiple of 32, pixel "
                     "stride a multiple of 4, 8-byte aligned tensors): %d channels, stride %lld", name, g.IC, (long long)g.ldi);
+    if constexpr (XSP)
+        SNN_REQUIRE(fast, "%s: covers the pipelined implicit GEMM only (input channels a multiple of 32, pixel stride a "
+                    "multiple of 4, 16-byte aligned tensors): %d channels, stride %lld", name, g.IC, (long long)g.ldi);
     // the pre-split weight image serves the pipelined kernel in its two-piece modes; every other path converts wk itself
     const bool presplit = wk_split != nullptr && (SPLIT == 2 || SPLIT == 4) && aligned16(wk_split);
 #define SNN_CONV_LAUNCH(BN_, WM_, WN_)                                                                      \
@@ -1446,6 +1493,9 @@ static int launch_gather(const float* in, const float* wk, const void* wk_split,
         dim3 grid((unsigned)(gg.mtiles_per_xcd * 8 * gg.ntiles));                                           \
         if constexpr (SB) {                                                                                 \
             hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, DGRAD, true, 5, true, false, true>), grid,     \
+                               dim3(kThreads), 0, st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);   \
+        } else if constexpr (XSP) {                                                                         \
+            hipLaunchKernelGGL((k_conv_gather<BN_, WM_, WN_, false, true, 4, true, false, false, true>), grid, \
                                dim3(kThreads), 0, st, in, wk, out, gg, addend, ld_add, addend2, ld_add2);   \
         } else if (fast && presplit) {                                                                      \
             if constexpr (SPLIT == 2 || SPLIT == 4)                                                         \
@@ -2265,7 +2315,7 @@ extern "C" int snn_conv2d_fwd(const float* x, int64_t ldx, const float* w, const
     g.nimg = (int)N;
     g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
     g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
-    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
+    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0; g.x_th = 0.0f;
     SNN_REQUIRE(N * (int64_t)H * W < 0x7fffffffLL && (int64_t)g.Ktot * Cin < 0xffffffffLL,
                 "snn_conv2d_fwd: tensor too large for 32-bit pixel indexing");
     SNN_REQUIRE(!addend || ld_addend >= Cout, "snn_conv2d_fwd: addend pixel stride smaller than channel count");
@@ -2524,9 +2574,10 @@ extern "C" int snn_conv2d_wgrad_bn(const float* x, int64_t ldx, const float* gx,
     return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * KH * KW * Cin, splitk, accumulate, (hipStream_t)stream);
 }
 
-extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
-                                int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
-                                int accumulate, float* workspace, int splitk, int precision, void* stream) {
+// xsp: x holds saved LIF potentials, the operand is z = (x > x_th) (snn_conv1x1_spikes_wgrad; pipelined bf16 x 3 kernel only)
+static int wgrad_common(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
+                        int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                        int accumulate, float* workspace, int splitk, int precision, void* stream, bool xsp, float x_th) {
     SNN_REQUIRE(x && dy && dw && workspace, "snn_conv2d_wgrad: null pointer");
     SNN_REQUIRE(precision == SNN_PREC_FP32 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16X1 ||
                     precision == SNN_PREC_BF16S,
@@ -2543,7 +2594,8 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
     g.ldx = ldx; g.lddy = lddy;
     g.Ktot = KH * KW * Cin;
-    if (first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, sbf)) {
+    g.x_th = x_th;
+    if (!xsp && first_layer_wgrad_ok(x, ldx, dy, lddy, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, sbf)) {
         FirstGeom fg = {ldx, lddy, (int)(N * Ho), H, W, Ho, Wo, Cout, stride, pad, (int)(N * Ho), splitk, nullptr,
                         nullptr, 0, nullptr, 0, 1, first_layer_rs(W, pad)};
         if (sbf)
@@ -2555,7 +2607,7 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
         return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
     }
-    if (bwd_split) {
+    if (bwd_split && !xsp) {
         const SnnWgradHaloPlan hp = snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad);
         if (hp.ok) {
             SNN_REQUIRE(splitk == hp.slabs, "snn_conv2d_wgrad: splitk %d, expected %d (snn_conv2d_wgrad_splitk)", splitk,
@@ -2585,6 +2637,8 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     const bool one = precision == SNN_PREC_BF16X1 || sbf;
     SNN_REQUIRE(!sbf || pipe, "snn_conv2d_wgrad: bf16 storage covers the event-frame layer and the pipelined kernels only "
                 "(channels and strides multiples of 4, 8-byte aligned tensors, < 2 GiB per pixel split)");
+    SNN_REQUIRE(!xsp || (pipe && !one), "snn_conv1x1_spikes_wgrad: covers the pipelined bf16 x 3 kernel only (channels and "
+                "strides multiples of 4, 16-byte aligned tensors, < 2 GiB per pixel split)");
     g.tiles_m = (int)snn_ceil_div(Cout, t.bm);
     g.tiles_n = (int)snn_ceil_div(g.Ktot, t.bn);
     g.splitk = splitk;
@@ -2594,7 +2648,13 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
     hipStream_t st = (hipStream_t)stream;
 #define SNN_WGRAD_LAUNCH(TM_, TN_, WM_, WN_)                                                                   \
     do {                                                                                                       \
-        if (sbf && wbk == 64)                                                                                  \
+        if (xsp && wbk == 64)                                                                                  \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, false, false, true>), grid, dim3(kThreads), 0, st, x, \
+                               dy, workspace, g);                                                              \
+        else if (xsp)                                                                                          \
+            hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 32, false, false, true>), grid, dim3(kThreads), 0, st, x, \
+                               dy, workspace, g);                                                              \
+        else if (sbf && wbk == 64)                                                                             \
             hipLaunchKernelGGL((k_conv_wgrad_pipe<TM_, TN_, WM_, WN_, 64, true, true>), grid, dim3(kThreads), 0, st, x, dy, \
                                workspace, g);                                                                  \
         else if (sbf)                                                                                          \
@@ -2628,4 +2688,52 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
 #undef SNN_WGRAD_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
     return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, st);
+}
+
+extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dw, int64_t N,
+                                int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                                int accumulate, float* workspace, int splitk, int precision, void* stream) {
+    return wgrad_common(x, ldx, dy, lddy, dw, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, accumulate, workspace, splitk,
+                        precision, stream, false, 0.0f);
+}
+
+// ---- 1x1 convolutions over spikes that were never stored (see k_conv_gather XSP, include/snn_hip.h)
+extern "C" int snn_conv1x1_spikes_supported(int64_t N, int H, int W, int Cin, int Cout, int64_t ld, int fwd_precision,
+                                            int bwd_precision) {
+    return (N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 4 == 0 && ld % 4 == 0 && ld >= Cin &&
+            fwd_precision == SNN_PREC_FP16X3 && bwd_precision == SNN_PREC_BF16X3 && N * (int64_t)H * W < 0x7fffffffLL &&
+            (int64_t)H * W * ld * 16 < 0x7fffffffLL) ? 1 : 0;
+}
+
+extern "C" int snn_conv1x1_spikes_fwd(const float* vdec, int64_t ld, float v_th, const float* w, float* y, int64_t ldy,
+                                      int64_t N, int H, int W, int Cin, int Cout, void* stream) {
+    SNN_REQUIRE(vdec && w && y, "snn_conv1x1_spikes_fwd: null pointer");
+    SNN_REQUIRE(v_th >= 0.0f, "snn_conv1x1_spikes_fwd: a negative threshold would turn padding into spikes");
+    if (check_conv_shape("snn_conv1x1_spikes_fwd", N, H, W, Cin, H, W, Cout, 1, 1, 1, 0)) return 1;
+    SNN_REQUIRE(snn_conv1x1_spikes_supported(N, H, W, Cin, Cout, ld, SNN_PREC_FP16X3, SNN_PREC_BF16X3) && ldy >= Cout,
+                "snn_conv1x1_spikes_fwd: shape not covered (ask snn_conv1x1_spikes_supported)");
+    ConvGeom g;
+    g.Mtot = N * H * (int64_t)W;
+    g.IH = H; g.IW = W; g.IC = Cin;
+    g.OH = H; g.OW = W; g.OC = Cout;
+    g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0;
+    g.ldi = ld; g.ldo = ldy;
+    g.Ktot = g.KtotFull = Cin;
+    g.nimg = (int)N;
+    g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = 1; g.nkw = 1; g.OHc = H; g.OWc = W;
+    g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(1);
+    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
+    g.x_th = v_th;
+    return launch_gather<false, 4, false, true>(vdec, w, nullptr, y, g, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+                                                "snn_conv1x1_spikes_fwd");
+}
+
+extern "C" int snn_conv1x1_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw,
+                                        int64_t N, int H, int W, int Cin, int Cout, int accumulate, float* workspace,
+                                        int splitk, void* stream) {
+    SNN_REQUIRE(v_th >= 0.0f, "snn_conv1x1_spikes_wgrad: a negative threshold would turn padding into spikes");
+    SNN_REQUIRE(snn_conv1x1_spikes_supported(N, H, W, Cin, Cout, ld, SNN_PREC_FP16X3, SNN_PREC_BF16X3),
+                "snn_conv1x1_spikes_wgrad: shape not covered (ask snn_conv1x1_spikes_supported)");
+    return wgrad_common(vdec, ld, dy, lddy, dw, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, accumulate, workspace, splitk,
+                        SNN_PREC_BF16X3, stream, true, v_th);
 }

@@ -390,9 +390,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
         // memory operations (at a control-flow join the compiler's wait-count pass falls back to vmcnt(0)), so it exists
         // in the two forms the layer-major step uses - BatchNorm affine, all T outputs, with / without a shortcut - and
         // everything else (no affine, last step only) takes the plain loop with its run-time checks.
-        auto time_loop = [&](auto piped_c, auto add_c) {
+        auto time_loop = [&](auto piped_c, auto add_c, auto noout_c) {
         constexpr bool PIPED = decltype(piped_c)::value;       // affine present, all outputs stored, ADD known
         constexpr bool ADD = decltype(add_c)::value;
+        // NOOUT (SNN_SCAN_SPIKES_FROM_VDEC; LIF without a shortcut, v_dec saved): no output tensor at all - the consumer
+        // forms the spikes itself, z = (v_dec > v_th), while it reads the saved potentials (snn_conv1x1_spikes_*)
+        constexpr bool NOOUT = decltype(noout_c)::value;
         constexpr int kPrefetch = PIPED ? SNN_SCAN_PREFETCH : 0;
         struct StepOps { V x, a, b, ad; };
         auto fetch_step = [&](int t) {
@@ -477,8 +480,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(cur.ad, j);
             }
-            if (PIPED || !last_only) VecS<VEC, SB>::store(out, row * ldo + c, o);
-            else if (t == T - 1) VecS<VEC, SB>::store(out, m * ldo + c, o);
+            if constexpr (!NOOUT) {
+                if (PIPED || !last_only) VecS<VEC, SB>::store(out, row * ldo + c, o);
+                else if (t == T - 1) VecS<VEC, SB>::store(out, m * ldo + c, o);
+            }
             if (SAVE == 1 && (NEURON == SNN_NEURON_LIF || NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE)) {
                 // (non-temporal where the access is one plain 16-byte store: nobody reads v_dec before the backward pass,
                 // while `out` is the next convolution's operand and should be what stays in the caches)
@@ -489,13 +494,15 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
         };
         if constexpr (VEC > 1 && SAVE != 2) {
             if (alpha && !last_only) {
-                if (addend) time_loop(std::true_type{}, std::true_type{});
-                else time_loop(std::true_type{}, std::false_type{});
+                if (addend) time_loop(std::true_type{}, std::true_type{}, std::false_type{});
+                else if (SAVE == 1 && NEURON == SNN_NEURON_LIF && !SB && out == nullptr)
+                    time_loop(std::true_type{}, std::false_type{}, std::true_type{});
+                else time_loop(std::true_type{}, std::false_type{}, std::false_type{});
             } else {
-                time_loop(std::false_type{}, std::false_type{});
+                time_loop(std::false_type{}, std::false_type{}, std::false_type{});
             }
         } else {
-            time_loop(std::false_type{}, std::false_type{});
+            time_loop(std::false_type{}, std::false_type{}, std::false_type{});
         }
         if (NEURON != SNN_NEURON_NONE) {
             if (vT) Vec<VEC>::store(vT + m * C + c, v);
@@ -1425,11 +1432,19 @@ static int neuron_fwd(int neuron, const float* y, int64_t ldy, const float* alph
                       const float* i0, float* out, int64_t ldo, const float* addend, int64_t ld_addend, float* vT,
                       float* iT, float* vdec, int ckpt_mode, int T, int64_t M, int C, const snn_neuron_params* p,
                       int flags, void* stream) {
-    SNN_REQUIRE(y && out && p, "snn_affine_neuron_fwd: null pointer");
-    SNN_REQUIRE((flags & ~(SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE)) == 0, "snn_affine_neuron_fwd: unknown flags 0x%x",
-                flags);
+    SNN_REQUIRE((flags & ~(SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE | SNN_SCAN_SPIKES_FROM_VDEC)) == 0,
+                "snn_affine_neuron_fwd: unknown flags 0x%x", flags);
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
     const bool sb = (flags & SNN_SCAN_BF16_STORAGE) != 0;   // y, out, addend, vdec are bf16 tensors
+    const bool no_out = (flags & SNN_SCAN_SPIKES_FROM_VDEC) != 0;   // no output tensor: the consumer thresholds vdec
+    SNN_REQUIRE(y && p && (out || no_out), "snn_affine_neuron_fwd: null pointer");
+    if (no_out) {
+        SNN_REQUIRE(neuron == SNN_NEURON_LIF && vdec && !ckpt_mode && !addend && !last_only && !sb && alpha && !out &&
+                        C % 4 == 0 && ldy % 4 == 0 && aligned16(y) && aligned16(vdec),
+                    "snn_affine_neuron_fwd: SNN_SCAN_SPIKES_FROM_VDEC is for Norm -> LIF with saved potentials, no shortcut, "
+                    "all T steps, fp32 tensors, 4-channel groups; out must be NULL");
+        ldo = C;   // (unused; keeps the checks below meaningful)
+    }
     SNN_REQUIRE(!last_only || ((neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH) &&
                                !addend),
                 "snn_affine_neuron_fwd: SNN_SCAN_LAST_STEP_ONLY is for LIF / LI / LI+Tanh without a shortcut");

@@ -515,6 +515,9 @@ def flush_counter_batch() -> None:
 FUSE_OUTER_ADDEND = not os.environ.get("SNN_NO_OUTER_ADDEND")  # bisecting aid
 # sibling 1x1 convolutions of one input (the C2f split) as ONE convolution (generator.BlockGen._plan_siblings)
 USE_SIBLING_FUSION = not os.environ.get("SNN_NO_SIBLING_FUSION")
+# a Norm -> LIF layer whose only consumer is such a convolution writes NO spike tensor: the consumer thresholds the saved
+# potentials itself (snn_conv1x1_spikes_*; SNN_NO_SPIKES_FROM_VDEC: tuning / bisecting aid)
+USE_SPIKES_FROM_VDEC = not os.environ.get("SNN_NO_SPIKES_FROM_VDEC")
 
 
 class GradAccumulator:
@@ -1070,7 +1073,9 @@ class _SiblingConv1x1(Function):
     branch contributions in another order."""
 
     @staticmethod
-    def forward(ctx, x, w1, dest, acc, prec, slot1, slots2, *w2s):
+    def forward(ctx, x, w1, dest, acc, prec, slot1, slots2, x_th, *w2s):
+        """``x_th`` (not None): ``x`` holds the saved potentials of the LIF layer in front (``affine_neuron(spikes_ok=True)``),
+        the operand is ``z = (x > x_th)``."""
         _require_device(x, "conv2d input", bf16_ok=True)
         fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         if x.dtype == _BF16:
@@ -1111,9 +1116,19 @@ class _SiblingConv1x1(Function):
             if w1m is None and need_t:
                 wct.copy_(wc.t())
         y = _out_tensor(dest, T, B, Ct, H, W, x)
-        _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), None, y.data_ptr(), cl_stride(y), T * B,
-                  H, W, Cin, H, W, Ct, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
+        if x_th is not None and not _hip.query("snn_conv1x1_spikes_supported", T * B, H, W, Cin, Ct, cl_stride(x), fwd_prec,
+                                               bwd_prec):
+            # (arithmetic or shape the thresholding kernels do not cover: the spikes are materialised after all)
+            x = _cl_view((x.permute(0, 1, 3, 4, 2) > x_th).to(_F32).contiguous())
+            x_th = None
+        if x_th is not None:
+            _hip.call("snn_conv1x1_spikes_fwd", x.data_ptr(), cl_stride(x), x_th, wc.data_ptr(), y.data_ptr(), cl_stride(y),
+                      T * B, H, W, Cin, Ct, _stream())
+        else:
+            _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), wc.data_ptr(), None, y.data_ptr(), cl_stride(y), T * B,
+                      H, W, Cin, H, W, Ct, 1, 1, 1, 0, None, 0, None, 0, None, fwd_prec, _stream())
         ctx.prec = bwd_prec
+        ctx.x_th = x_th
         ctx.save_for_backward(x, w1m, *w2ms)
         ctx.wct = wct
         ctx.geom = (T, B, Cin, H, W, Ct, 1, 1, H, W, 1, 0)
@@ -1135,7 +1150,7 @@ class _SiblingConv1x1(Function):
         dw2s = [None] * len(widths)
         if ctx.needs_input_grad[0]:
             dx = _dgrad_accumulate(ctx.acc, gy, ldg, ctx.wct, x, ctx.geom, st, ctx.prec)
-        if any(ctx.needs_input_grad[7:]) or (composed and ctx.needs_input_grad[1]):
+        if any(ctx.needs_input_grad[8:]) or (composed and ctx.needs_input_grad[1]):
             slot1, slots2 = ctx.slot1, ctx.slots2
             slotted = all(s_ is not None for s_ in slots2) and (slot1 is not None or not composed)
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, H, W, Ct, 1, 1, 1, 0, ctx.prec)
@@ -1148,8 +1163,12 @@ class _SiblingConv1x1(Function):
             with torch.cuda.stream(stream):
                 ws = torch.empty((splitk, Ct * Cin), device=x.device, dtype=_F32)
                 G = torch.empty((Ct, Cin), device=x.device, dtype=_F32)
-                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
-                          W, Ct, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, ctx.prec, stream.cuda_stream)
+                if ctx.x_th is not None:   # x holds the potentials of the LIF layer in front: thresholded on load
+                    _hip.call("snn_conv1x1_spikes_wgrad", x.data_ptr(), ldx, ctx.x_th, gy.data_ptr(), ldg, G.data_ptr(),
+                              T * B, H, W, Cin, Ct, 0, ws.data_ptr(), splitk, stream.cuda_stream)
+                else:
+                    _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, G.data_ptr(), T * B, H, W, Cin, H,
+                              W, Ct, 1, 1, 1, 0, 0, ws.data_ptr(), splitk, ctx.prec, stream.cuda_stream)
                 g1 = None
                 if composed:
                     g1 = slot1.buf.view(C1, Cin) if slotted else torch.empty((C1, Cin), device=x.device, dtype=_F32)
@@ -1176,7 +1195,7 @@ class _SiblingConv1x1(Function):
                     dw1 = g1.view(C1, Cin, 1, 1)
             if side_ok:
                 _side_hold(stream, x, gy)
-        return (dx, dw1, None, None, None, None, None, *dw2s)
+        return (dx, dw1, None, None, None, None, None, None, *dw2s)
 
 
 def sibling_conv1x1(x: torch.Tensor, w1: Optional[torch.Tensor], w2s: Sequence[torch.Tensor], dest: Optional[Dest] = None,
@@ -1184,7 +1203,8 @@ def sibling_conv1x1(x: torch.Tensor, w1: Optional[torch.Tensor], w2s: Sequence[t
     """``cat([conv1x1(h, w) for w in w2s], channels)`` with ``h = conv1x1(x, w1)`` (``h = x`` when ``w1`` is None), as one
     convolution; ``x`` is a sequence ``[T,B,C,H,W]``."""
     return _SiblingConv1x1.apply(x, w1, dest, _acc_of(x), _prec_codes(forward_precision, backward_precision),
-                                 _slot_of(w1), tuple(_slot_of(w) for w in w2s), *w2s)
+                                 _slot_of(w1), tuple(_slot_of(w) for w in w2s), getattr(x, "_snn_spike_threshold", None),
+                                 *w2s)
 
 
 class BnPartial(NamedTuple):
@@ -1270,7 +1290,7 @@ class _AffineNeuron(Function):
     @staticmethod
     def forward(ctx, y, gamma, bias, v0, i0, addend, cfg):
         (neuron, has_bn, training, eps, momentum, running_mean, running_var, params, g_slot, b_slot, dest,
-         sync_group, bn_hint, last_only, defer_apply) = cfg
+         sync_group, bn_hint, last_only, defer_apply, spikes_out) = cfg
         _require_device(y, "norm/neuron input", bf16_ok=True)
         sb = y.dtype == _BF16   # bf16 storage: y, out, the saved per-step state and the gradients; (v, i) and all sums fp32
         if sb and (neuron not in (_hip.NEURON_NONE, _hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH) or y.shape[-3] % 4):
@@ -1324,18 +1344,26 @@ class _AffineNeuron(Function):
                     _hip.call("snn_bn_stats_from_sums", sums.data_ptr(), T, M * world, C, g_ptr, b_ptr, eps, momentum,
                               _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
                               alpha.data_ptr(), beta.data_ptr(), scratch.data_ptr(), st)
+        need_grad = any(ctx.needs_input_grad[:5])
+        # spikes_out (a list the caller reads afterwards): the consumer can form the spikes from the saved potentials
+        # (snn_conv1x1_spikes_*), so when those are saved anyway no output tensor is written at all
+        no_out = (spikes_out is not None and USE_SPIKES_FROM_VDEC and neuron == _hip.NEURON_LIF and need_grad and has_bn
+                  and addend is None and dest is None and not last_only and not sb and C % 4 == 0 and ldy % 4 == 0
+                  and params.v_th >= 0.0
+                  and not (LIF_CHECKPOINT_BYTES is not None and T * M * C * 4 >= LIF_CHECKPOINT_BYTES))
         if last_only:
             # only the last timestep's output is kept (snn_affine_neuron_fwd SNN_SCAN_LAST_STEP_ONLY): out is [B,C,H,W]
             if (neuron not in (_hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH) or addend is not None
                     or dest is not None):
                 raise RuntimeError("last_only is for LIF / LI / LI+Tanh without shortcut or concat destination")
             out = _new_cl((B,), C, H, W, y)
+        elif no_out:
+            out = None
         else:
             out = _out_tensor(dest, T, B, C, H, W, y)
         has_state = neuron != _hip.NEURON_NONE
         vT = _new_cl((B,), C, H, W, y, _F32) if has_state else torch.empty(0, device=dev)
         iT = _new_cl((B,), C, H, W, y, _F32) if has_state else torch.empty(0, device=dev)
-        need_grad = any(ctx.needs_input_grad[:5])
         vdec = None
         ckpt = False
         if neuron in _SAVES_STEP and need_grad:
@@ -1369,9 +1397,15 @@ class _AffineNeuron(Function):
                       params, st)
         else:
             _hip.call("snn_affine_neuron_fwd", neuron, y.data_ptr(), ldy, _ptr(alpha), _ptr(beta), _ptr(v0), _ptr(i0),
-                      out.data_ptr(), cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
+                      _ptr(out), C if out is None else cl_stride(out), ad_ptr, ld_ad, _ptr(vT) if has_state else None,
                       _ptr(iT) if has_state else None, _ptr(vdec), T, M, C, params,
-                      (_hip.SCAN_LAST_STEP_ONLY if last_only else 0) | sb_flag, st)
+                      (_hip.SCAN_LAST_STEP_ONLY if last_only else 0) | sb_flag
+                      | (_hip.SCAN_SPIKES_FROM_VDEC if no_out else 0), st)
+            if no_out:
+                # what travels to the consumer is an alias of the saved potentials, marked with the threshold that turns
+                # them into this layer's output
+                out = _alias(vdec, vdec.storage_offset(), T, B, C, H, W, C)
+                spikes_out.append(float(params.v_th))
         ctx.ckpt = ckpt
         ctx.sb = sb
         ctx.defer_apply = defer_apply
@@ -1542,8 +1576,11 @@ def _expand_state(s: torch.Tensor, shape, dev) -> torch.Tensor:
 
 def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = None, bn=None,
                   params: Optional[NeuronParams] = None, dest: Optional[Dest] = None,
-                  addend: Optional[torch.Tensor] = None, last_only: bool = False):
+                  addend: Optional[torch.Tensor] = None, last_only: bool = False, spikes_ok: bool = False):
     """Fused ``[Norm] -> [neuron] [+ addend]`` over a sequence or a single step.
+
+    ``spikes_ok`` (LIF on a sequence; the caller guarantees that the ONLY consumer is ``sibling_conv1x1``): the result may be
+    the layer's saved potentials instead of its spikes, marked ``_snn_spike_threshold`` - no spike tensor is written.
 
     ``bn`` is an ``nn.BatchNorm2d``-like module (weight, bias, running stats, eps, momentum, training)
     or None; ``addend`` (same shape as the output) is a residual shortcut added in the output store.
@@ -1555,7 +1592,7 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
                              or y.shape[-3] % 4):
         # no bf16-storage form of this scan (SLI / Synapse, channel counts that are not a multiple of 4): see _through_fp32
         out, new_state = affine_neuron(to_float32(y), neuron, state, bn, params, None,
-                                       None if addend is None else to_float32(addend), last_only)
+                                       None if addend is None else to_float32(addend), last_only, False)
         out = out if (last_only and y.dim() == 5) else to_bfloat16(out)
         return (place(out, dest) if dest is not None else out), new_state
     bn_hint = getattr(y, "_snn_bn_partial", None)
@@ -1595,9 +1632,12 @@ def affine_neuron(y: torch.Tensor, neuron: int, state: Optional[NeuronState] = N
         else:
             v0, i0 = state
     sync_group = getattr(bn, "_snn_sync_group", None) if has_bn else None
+    spikes_out = [] if (spikes_ok and not single and dest is None and addend is None) else None
     cfg = (neuron, has_bn, training, float(eps), float(momentum), rm, rv, params, _slot_of(gamma), _slot_of(bias),
-           dest, sync_group, bn_hint, bool(last_only) and not single, defer_apply)
+           dest, sync_group, bn_hint, bool(last_only) and not single, defer_apply, spikes_out)
     out, vT, iT = _AffineNeuron.apply(seq, gamma, bias, v0, i0, addend, cfg)
+    if spikes_out:
+        out._snn_spike_threshold = spikes_out[0]   # `out` holds v_dec: its consumer thresholds on load
     if neuron == _hip.NEURON_NONE:
         new_state = None
     elif neuron == _hip.NEURON_SYNAPSE:

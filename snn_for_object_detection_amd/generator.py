@@ -265,9 +265,13 @@ class BlockGen(nn.Module):
         if self.merge == "dense" and zero_copy and promise is None:
             promise = HF.ConcatPromise(self.out_channels, parent=dest)
         siblings = None
+        spike_coded = getattr(X, "_snn_spike_threshold", None) is not None
         if (self._siblings is not None and zero_copy and HF.USE_SIBLING_FUSION and X.is_cuda
                 and (X.dtype != torch.bfloat16 or all(c % 32 == 0 for c in (self.in_channels, *(s[1] for s in self._siblings))))):
             inputs, siblings = self._run_siblings(X, promise, pre_conv)
+        elif spike_coded:
+            raise RuntimeError("internal error: a tensor of saved potentials (spikes never written) reached a block that does "
+                               "not open with the fused sibling convolution")
         else:
             inputs = HF.fanout(X, len(self.net))
         for b, (branch, flags, plan, branch_state) in enumerate(zip(self.net, self.branch_state, self._plan, state)):
@@ -313,8 +317,14 @@ class BlockGen(nn.Module):
                                  and shortcut is None
                                  and neuron in (_hip.NEURON_LIF, _hip.NEURON_LI, _hip.NEURON_LI_TANH)
                                  and not (isinstance(holder, StateStorage) and not self.training))
+                    # the only consumer is the fused sibling convolution of the next block (the stage-entry Conv -> Norm -> LIF
+                    # in front of a C2f split): it can form the spikes from the saved potentials, none are written
+                    spikes_ok = (zero_copy and not last and self.training and neuron == _hip.NEURON_LIF
+                                 and direct is None and shortcut is None and not isinstance(holder, StateStorage)
+                                 and plan[k + 1][0] == "conv_block" and branch[plan[k + 1][1] + 1]._siblings is not None
+                                 and HF.USE_SIBLING_FUSION and HF.USE_SPIKES_FROM_VDEC)
                     Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct,
-                                              addend=shortcut, last_only=only_last)
+                                              addend=shortcut, last_only=only_last, spikes_ok=spikes_ok)
                     if isinstance(holder, StateStorage):
                         holder.record(old, Y, new)
                     branch_state[idx + 1] = new

@@ -67,6 +67,15 @@ def work_of(name: str, a):
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
         byts = (4.0 if cin == 2 else es) * n * h * w * cin + es * n * ho * wo * cout + 4.0 * cout * kh * kw * cin
         return _conv_label(name, a) + (", bf16s" if sb else ""), flops, byts
+    if name in ("snn_conv1x1_spikes_fwd", "snn_conv1x1_spikes_wgrad"):   # 1x1 over spikes formed from saved potentials
+        fwd = name.endswith("_fwd")
+        n, h, w, cin, cout = (a[6], a[7], a[8], a[9], a[10])
+        flops = 2.0 * n * h * w * cout * cin
+        byts = 4.0 * (n * h * w * cin + n * h * w * cout + cout * cin)
+        if not fwd:
+            return "k_conv_wgrad", flops, byts
+        tile = "32, 4, 1" if cout <= 32 else ("64, 2, 2" if cout <= 64 else "128, 2, 2")
+        return f"k_conv_gather<{tile}, false, true>", flops, byts
     if name == "snn_conv3x3_halo":   # halo-resident 3x3 / stride 1 (csrc/conv_halo.hip): forward (fp16 x 3) or data gradient
         n, h, w, cin, cout, prec = a[5], a[6], a[7], a[8], a[9], a[17]
         es = 2.0 if prec == PREC_BF16S else 4.0
@@ -95,7 +104,8 @@ def work_of(name: str, a):
         last_only = bool(a[18] & 2)   # SNN_SCAN_LAST_STEP_ONLY: the output of ONE step is written
         elems = float(T) * M * C
         # y read; out written (one step of it with last_only); + vdec, + fused shortcut
-        tensors = 1 + (1.0 / T if last_only else 1) + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)
+        wrote_out = 0 if a[7] is None else (1.0 / T if last_only else 1)   # (SNN_SCAN_SPIKES_FROM_VDEC: no output tensor)
+        tensors = 1 + wrote_out + (1 if a[13] is not None else 0) + (1 if a[9] is not None else 0)
         sb = bool(a[18] & SCAN_BF16_STORAGE)
         return f"k_affine_neuron_fwd<{neuron}>" + (", bf16s" if sb else ""), 12.0 * elems, (2.0 if sb else 4.0) * elems * tensors
     if name == "snn_affine_neuron_bwd":

@@ -100,7 +100,9 @@ def test_fused_siblings_equal_the_separate_convolutions(S, c, n, H, W):
     # ONE forward convolution, ONE data gradient and ONE pixel reduction for the pair - and no gather copy: the joined
     # gradient is a channel slice of the concat gradient (pixel stride = concat width)
     width = (n + 2) * c // 2
-    fwd = [a for nm, a in calls if nm == "snn_conv2d_fwd" and a[14] == 1 and a[15] == 1 and a[12] == c and a[9] == c]
+    # (behind a stage-entry LIF the fused convolution reads saved potentials: snn_conv1x1_spikes_fwd, same position of ldy)
+    fwd = [a for nm, a in calls if (nm == "snn_conv2d_fwd" and a[14] == 1 and a[15] == 1 and a[12] == c and a[9] == c)
+           or (nm == "snn_conv1x1_spikes_fwd" and a[9] == c and a[10] == c)]
     assert len(fwd) == 1 and fwd[0][5] == width      # writes c channels into the concat buffer
     dg = [a for nm, a in calls if nm == "snn_conv2d_dgrad" and a[13] == 1 and a[12] == c and a[9] == c]
     assert len(dg) == 1 and dg[0][1] == width, [a[1] for a in dg]
@@ -184,3 +186,97 @@ def test_data_gradient_accumulates_in_place_over_its_second_addend(hip_lib):
         torch.cuda.synchronize()
         want_buf[..., off:off + C] = ref
         assert torch.equal(buf, want_buf), (C, k)      # the slice holds the sum, the rest of the buffer is untouched
+
+
+# ------------------------------------------------------------------------------------------- spikes that are never stored
+@pytest.mark.parametrize("Cin,Cout,N,H,W,ld", [(64, 64, 6, 24, 40, 64), (128, 128, 4, 15, 19, 128), (256, 256, 3, 8, 10, 256),
+                                               (32, 96, 5, 9, 13, 32), (64, 32, 2, 30, 38, 96)],
+                         ids=["64-64", "128-128", "256-256-small", "32-96-odd", "64-32-sliced"])
+def test_spike_kernels_equal_the_plain_kernels_on_stored_spikes(hip_lib, Cin, Cout, N, H, W, ld):
+    """snn_conv1x1_spikes_fwd / _wgrad read saved potentials and threshold on load (two MFMA products: the low piece of a
+    spike is zero): bit for bit what snn_conv2d_fwd / snn_conv2d_wgrad give on the stored spike tensor."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from snn_for_object_detection_amd import _hip
+    g = torch.Generator().manual_seed(11)
+    v_th = 1.0
+    vdec_wide = (1.0 + 0.8 * torch.randn(N, H, W, ld, generator=g)).cuda()
+    vdec_wide[0, 0, 0, :4] = torch.tensor([1.0, 1.0 + 2 ** -23, 1.0 - 2 ** -24, 0.0])   # exactly at / next to the threshold
+    z = (vdec_wide > v_th).float()
+    w = (0.2 * torch.randn(Cout, Cin, generator=g)).cuda()
+    dy = torch.randn(N, H, W, Cout, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    assert _hip.query("snn_conv1x1_spikes_supported", N, H, W, Cin, Cout, ld, _hip.PREC_FP16X3, _hip.PREC_BF16X3)
+    y_ref, y_new = torch.empty(N, H, W, Cout, device="cuda"), torch.empty(N, H, W, Cout, device="cuda")
+    _hip.call("snn_conv2d_fwd", z.data_ptr(), ld, w.data_ptr(), None, y_ref.data_ptr(), Cout, N, H, W, Cin, H, W, Cout, 1, 1,
+              1, 0, None, 0, None, 0, None, _hip.PREC_FP16X3, st)
+    _hip.call("snn_conv1x1_spikes_fwd", vdec_wide.data_ptr(), ld, v_th, w.data_ptr(), y_new.data_ptr(), Cout, N, H, W, Cin,
+              Cout, st)
+    assert torch.equal(y_new, y_ref)
+    rel = float((y_ref.double() - torch.einsum("nhwc,oc->nhwo", z[..., :Cin].double(), w.double())).norm()
+                / y_ref.double().norm())
+    assert rel < 1e-6, rel
+    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, _hip.PREC_BF16X3)
+    ws = torch.empty(splitk, Cout * Cin, device="cuda")
+    g_ref, g_new = torch.empty(Cout, Cin, device="cuda"), torch.full((Cout, Cin), 0.5, device="cuda")
+    _hip.call("snn_conv2d_wgrad", z.data_ptr(), ld, dy.data_ptr(), Cout, g_ref.data_ptr(), N, H, W, Cin, H, W, Cout, 1, 1, 1,
+              0, 0, ws.data_ptr(), splitk, _hip.PREC_BF16X3, st)
+    _hip.call("snn_conv1x1_spikes_wgrad", vdec_wide.data_ptr(), ld, v_th, dy.data_ptr(), Cout, g_new.data_ptr(), N, H, W,
+              Cin, Cout, 1, ws.data_ptr(), splitk, st)                     # accumulate onto 0.5
+    assert torch.equal(g_new, g_ref + 0.5)
+    # refusals: arithmetic / shapes the thresholding kernels do not cover
+    assert not _hip.query("snn_conv1x1_spikes_supported", N, H, W, Cin + 8, Cout, ld + 8, _hip.PREC_FP16X3, _hip.PREC_BF16X3)
+    assert not _hip.query("snn_conv1x1_spikes_supported", N, H, W, Cin, Cout, ld, _hip.PREC_FP32, _hip.PREC_FP32)
+    with pytest.raises(RuntimeError, match="negative threshold"):
+        _hip.call("snn_conv1x1_spikes_fwd", vdec_wide.data_ptr(), ld, -0.5, w.data_ptr(), y_new.data_ptr(), Cout, N, H, W, Cin,
+                  Cout, st)
+
+
+def test_stage_entry_lif_writes_no_spike_tensor_and_nothing_changes(S):
+    """Conv -> Norm -> LIF in front of a C2f split: with USE_SPIKES_FROM_VDEC the scan writes only the potentials it saves
+    anyway and the fused sibling convolution thresholds them on load - outputs and every gradient bit for bit those of the
+    path that stores the spikes; in exact-fp32 arithmetic (not covered by the thresholding kernels) the spikes are stored."""
+    from snn_for_object_detection_amd import _hip
+    HF = S.functional
+    T, B, H, W, c, n = 4, 2, 24, 40, 64, 2
+    blk = _build(S, _c2f(S, c, n), True)
+    x = synthetic_events(T, B, H, W, p=0.3, seed=1).cuda()
+    probe = torch.randn(T, B, c, H // 2, W // 2, generator=torch.Generator().manual_seed(4)).cuda()
+
+    def run(on):
+        was = HF.USE_SPIKES_FROM_VDEC
+        HF.USE_SPIKES_FROM_VDEC = on
+        calls = []
+
+        class Spy:
+            def before(self, name, args):
+                calls.append((name, args))
+
+            def after(self, tok):
+                pass
+        _hip.PROFILER = Spy()
+        try:
+            return _run(S, blk, x, True, probe), calls
+        finally:
+            _hip.PROFILER = None
+            HF.USE_SPIKES_FROM_VDEC = was
+    (y1, gx1, g1), calls1 = run(True)
+    (y0, gx0, g0), calls0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    names1, names0 = [nm for nm, _ in calls1], [nm for nm, _ in calls0]
+    assert names1.count("snn_conv1x1_spikes_fwd") == 1 and names1.count("snn_conv1x1_spikes_wgrad") == 1
+    assert "snn_conv1x1_spikes_fwd" not in names0
+    entry = [a for nm, a in calls1 if nm == "snn_affine_neuron_fwd" and a[7] is None]
+    assert len(entry) == 1 and entry[0][18] & _hip.SCAN_SPIKES_FROM_VDEC       # ONE scan without an output tensor
+    assert not [a for nm, a in calls0 if nm == "snn_affine_neuron_fwd" and a[7] is None]
+    HF.set_forward_precision("fp32")
+    HF.set_backward_precision("fp32")
+    try:
+        (y2, _, _), calls2 = run(True)
+    finally:
+        HF.set_forward_precision(HF.DEFAULT_FORWARD_PRECISION)
+        HF.set_backward_precision(HF.DEFAULT_BACKWARD_PRECISION)
+    assert "snn_conv1x1_spikes_fwd" not in [nm for nm, _ in calls2]
+    assert float((y2 - y0).abs().max()) < 1e-4
