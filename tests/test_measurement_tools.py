@@ -48,6 +48,18 @@ def test_every_profiled_kernel_maps_to_a_family_with_launches(stats):
         assert pmc.family(name, bf16s).startswith("k_conv_wgrad") and not pmc.counts_as_launch(name)
 
 
+def test_event_frame_weight_gradient_instances_belong_to_the_weight_gradient_family():
+    """``k_conv_first<CIN, KS, WGRAD, BNAPPLY, SB>``: the third template argument decides (round 3's rule looked for a
+    trailing ``true>`` and filed the weight gradient ``<2, 3, true, true, false>`` under the forward kernel: 1.6 GB per step in
+    the wrong row)."""
+    fwd = "void (anonymous namespace)::k_conv_first<2, 3, false, false, false>(float const*, float const*)"
+    wg = "void (anonymous namespace)::k_conv_first<2, 3, true, true, false>(float const*, float const*)"
+    wg_sb = "void (anonymous namespace)::k_conv_first<2, 3, true, false, true>(float const*, float const*)"
+    assert pmc.family(fwd, False) == "k_conv_first<2, 3, false>"
+    assert pmc.family(wg, False) == "k_conv_wgrad" and pmc.family(wg_sb, True) == "k_conv_wgrad, bf16s"
+    assert pmc.counts_as_launch(wg)
+
+
 def test_a_helper_without_its_main_kernel_is_an_error_not_a_silent_drop():
     fetch = {"void k_wgrad_reduce4<4>(float*)": [100.0, 3]}
     with pytest.raises(RuntimeError, match="no launch-counting kernel"):

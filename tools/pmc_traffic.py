@@ -75,8 +75,10 @@ def _family(name: str, bf16s: bool) -> str:
         return f"k_conv_halo3<{t.group(1)}, {'fwd' if t.group(2) == 'true' else 'dgrad'}>" if t else base
     if base == "k_conv_s2dgrad3":
         return "k_conv_s2dgrad3<dgrad>"
-    if base == "k_conv_first":  # <CIN, KS, WGRAD>: the weight-gradient instance belongs to snn_conv2d_wgrad
-        return "k_conv_wgrad" if re.search(r"k_conv_first<[^>]*true>", name) else "k_conv_first<2, 3, false>"
+    if base == "k_conv_first":  # <CIN, KS, WGRAD, BNAPPLY, SB>: the weight-gradient instances belong to snn_conv2d_wgrad
+        t = re.search(r"k_conv_first<([^>]*)>", name)
+        args = [a.strip() for a in t.group(1).split(",")] if t else []
+        return "k_conv_wgrad" if len(args) > 2 and args[2] == "true" else "k_conv_first<2, 3, false>"
     if base in ("k_affine_neuron_fwd", "k_affine_neuron_bwd"):   # <NEURON, ...>: profiler.py labels the neuron
         t = re.search(base + r"<(\d+)", name)
         return f"{base}<{t.group(1)}>" if t else base
