@@ -54,7 +54,7 @@ PRODUCT_BITS = {"fp32": 24, "fp16x3": 22, "bf16x6": 24, "bf16x3": 16, "bf16": 8}
 def mfma_peak_for(kernel: str, fwd_prec: str, bwd_prec: str):
     """Peak ALGORITHMIC TFLOP/s of a conv kernel: the split-precision kernels spend 3 (bf16x3 / fp16x3) or 6 (bf16x6)
     dense 16-bit MFMA products per algorithmic multiply-add, the exact kernels one fp32 MFMA product."""
-    backward = (kernel.startswith("k_conv_wgrad") or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
+    backward = (kernel.startswith("k_conv_wgrad") or "wgrad" in kernel or ", true, " in kernel  # k_conv_gather<BN, WM, WN, DGRAD, VEC>
                 or kernel.endswith(", true>")     # k_conv_direct3<BN, WM, WN, DGRAD>
                 or "dgrad" in kernel)             # k_conv_halo3<CO, dgrad>, k_conv_s2dgrad3
     prec = bwd_prec if backward else fwd_prec
@@ -113,6 +113,22 @@ def chain_row(table, neuron_steps, profiled_steps, sb):
             "ideal_bytes_per_neuron_timestep": per, "moved_bytes_per_neuron_timestep": moved / neuron_steps,
             "traffic_ratio": moved / ideal, "gbs": gbs, "frac_hbm": gbs / PEAK_HBM_GBS,
             "basis": "SURVEY 8(d): fused Norm+LIF kernel alone = 5 x s bytes per neuron-timestep"}
+
+
+def wgrad_family_row(table, total_ms, profiled_steps):
+    """All weight-gradient kernels as ONE row (what rounds 1-3 called the k_conv_wgrad family): the implicit GEMM of the 1x1
+    layers (HBM-bound), the halo-resident 3x3 kernel (matrix-bound) and the event-frame row kernel are priced separately
+    above; the sum keeps the round-over-round comparison."""
+    keys = [k for k in table if k.split(",")[0] in ("k_conv_wgrad_pipe", "k_conv_wgrad_halo", "k_conv_first<wgrad>")]
+    ms = sum(table[k]["ms"] for k in keys)
+    if ms <= 0:
+        return None
+    flops, byts, calls = (sum(table[k][f] for k in keys) for f in ("flops", "bytes", "calls"))
+    sec = ms * 1e-3
+    return {"kernel": "k_conv_wgrad (all weight-gradient kernels + their ordered reduce)", "members": sorted(keys),
+            "ms_per_step": ms / profiled_steps, "share": ms / total_ms, "launches_per_step": calls // profiled_steps,
+            "tflops": flops / sec / 1e12, "gbs": byts / sec / 1e9, "frac_hbm": byts / sec / 1e9 / PEAK_HBM_GBS,
+            "frac_mfma": flops / sec / 1e12 / (PEAK_BF16_MATRIX_TFLOPS / 3.0)}
 
 
 def synthetic_batch(T, B, H, W, num_classes, device, seed, p=0.05):
@@ -568,7 +584,7 @@ def main():
                                if k.startswith("k_conv") else None),
                  "bound": roofline_head(k, r, args.forward_precision, args.backward_precision, sb)["bound"]}
                 for k, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if r["ms"] / total_ms >= 0.02]
-                + [c for c in [chain_row(table, prof.neuron_steps, 2, sb)] if c],
+                + [c for c in [chain_row(table, prof.neuron_steps, 2, sb), wgrad_family_row(table, total_ms, 2)] if c],
             "timing": "HIP events around every C-ABI launch on its launch stream, weight-gradient side stream and head "
                       "streams off (every kernel alone on the GPU)",
         }

@@ -239,6 +239,10 @@ int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, int64_t lddy,
  * floats); same geometry arguments as snn_conv2d_wgrad; host-only, callable without a device */
 int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                             int stride, int pad, int precision);
+/* which kernel snn_conv2d_wgrad takes for this shape: 0 implicit GEMM (k_conv_wgrad_pipe), 1 halo-resident
+ * (k_conv_wgrad_halo), 2 event-frame row kernel (k_conv_first); host-only - labels of the measurement tools */
+int snn_conv2d_wgrad_kernel(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                            int precision);
 /* ---- 1x1 convolutions over spikes that were never stored.  The stage-entry layers of the generated nets are
  * Conv -> Norm -> LIF feeding only 1x1 convolutions (reference models/tiny_yolo.py:76-85 behind :16-21); their LIF
  * (models/modules/layer_gen.py:232-235) saves v_dec for its backward pass anyway, so the spike tensor z = (v_dec > v_th)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "snn_conv2d_wgrad": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I,
                                  _P]),
     "snn_conv2d_wgrad_splitk": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "snn_conv2d_wgrad_kernel": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "snn_conv1x1_spikes_supported": (c_int, [_L, _I, _I, _I, _I, _L, _I, _I]),
     "snn_conv1x1_spikes_fwd": (c_int, [_P, _L, _F, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
     "snn_conv1x1_spikes_wgrad": (c_int, [_P, _L, _F, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),

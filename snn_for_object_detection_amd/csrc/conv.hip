@@ -2503,6 +2503,16 @@ extern "C" int snn_conv2d_wgrad_splitk(int64_t N, int H, int W, int Cin, int Ho,
     return (int)s;
 }
 
+// which kernel snn_conv2d_wgrad launches for a shape: 0 the implicit GEMM (k_conv_wgrad_pipe / k_conv_wgrad), 1 the
+// halo-resident kernel (k_conv_wgrad_halo), 2 the event-frame row kernel (k_conv_first) - for measurement labels; host-only
+extern "C" int snn_conv2d_wgrad_kernel(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                       int pad, int precision) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return 0;
+    if (first_layer_shape(Cin, Cout, KH, KW)) return 2;
+    if (precision != SNN_PREC_FP32 && snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad).ok) return 1;
+    return 0;
+}
+
 // dw (+)= sum over the splitk workspace slabs, fixed order
 static int wgrad_reduce_slabs(float* workspace, float* dw, int64_t n, int splitk, int accumulate, hipStream_t st) {
     if (n % 4 == 0 && aligned16(workspace) && aligned16(dw) && splitk > 8) {

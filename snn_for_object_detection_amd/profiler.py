@@ -19,9 +19,20 @@ from typing import Dict
 import torch
 
 
+WGRAD_LABELS = ("k_conv_wgrad_pipe", "k_conv_wgrad_halo", "k_conv_first<wgrad>")   # snn_conv2d_wgrad_kernel's 0, 1, 2
+
+
+def _wgrad_label(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, prec) -> str:
+    """The three weight-gradient kernels are different programs with different roofs (the implicit GEMM of the 1x1 layers is
+    HBM-bound, the halo-resident 3x3 kernel matrix-bound, the event-frame row kernel streams): one label each (+ its
+    ordered split-K reduce).  Round 3 priced them as ONE family."""
+    from . import _hip
+    return WGRAD_LABELS[int(_hip.query("snn_conv2d_wgrad_kernel", n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, prec))]
+
+
 def _conv_label(name: str, a) -> str:
     if name == "snn_conv2d_wgrad":
-        return "k_conv_wgrad"  # all tile variants of the weight-gradient kernel (+ its ordered reduce)
+        return _wgrad_label(a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[19])
     # fwd / dgrad share k_conv_gather<BN, WM, WN, DGRAD, VEC>
     dgrad = name == "snn_conv2d_dgrad"
     cin, cout = a[8], a[11]
@@ -73,7 +84,7 @@ def work_of(name: str, a):
         flops = 2.0 * n * h * w * cout * cin
         byts = 4.0 * (n * h * w * cin + n * h * w * cout + cout * cin)
         if not fwd:
-            return "k_conv_wgrad", flops, byts
+            return WGRAD_LABELS[0], flops, byts
         tile = "32, 4, 1" if cout <= 32 else ("64, 2, 2" if cout <= 64 else "128, 2, 2")
         return f"k_conv_gather<{tile}, false, true>", flops, byts
     if name == "snn_conv3x3_halo":   # halo-resident 3x3 / stride 1 (csrc/conv_halo.hip): forward (fp16 x 3) or data gradient
@@ -98,7 +109,7 @@ def work_of(name: str, a):
         n, h, w, cin, ho, wo, cout, kh, kw = a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18]
         flops = 2.0 * n * ho * wo * cout * kh * kw * cin
         byts = 4.0 * (n * h * w * cin + 2 * n * ho * wo * cout + cout * kh * kw * cin)   # x, gx and y are read
-        return "k_conv_wgrad", flops, byts
+        return WGRAD_LABELS[2], flops, byts
     if name == "snn_affine_neuron_fwd":
         neuron, T, M, C = a[0], a[14], a[15], a[16]
         last_only = bool(a[18] & 2)   # SNN_SCAN_LAST_STEP_ONLY: the output of ONE step is written

@@ -35,8 +35,12 @@ import sys
 
 BF16S = False   # "bf16s": the passes ran bench.py --storage bf16; labels get profiler.py's ", bf16s" suffix
 
-# helper kernels: prefix of the kernel's base name -> the family whose calls launch them
-HELPERS = {"k_wgrad_reduce": "k_conv_wgrad"}
+# helper kernels: prefix of the kernel's base name -> the family whose calls launch them.  The ordered split-K reduce runs
+# behind all three weight-gradient kernels (different programs with different roofs: round 4 prices them separately); the
+# raw pass tags every reduce launch with the kernel it followed in dispatch order ("... [after k_conv_wgrad_halo]"), an
+# untagged one (counter files of before) counts for the implicit GEMM.
+HELPERS = {"k_wgrad_reduce": "k_conv_wgrad_pipe"}
+WGRAD_FAMILIES = ("k_conv_wgrad_pipe", "k_conv_wgrad_halo", "k_conv_first<wgrad>")
 
 
 def base_name(name: str) -> str:
@@ -62,9 +66,10 @@ def family(name: str, bf16s: bool = None) -> str:
 def _family(name: str, bf16s: bool) -> str:
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     base = base_name(name)
+    tagged = re.search(r"\[after ([^\]]+)\]", name)
     for helper, fam in HELPERS.items():
         if base.startswith(helper):
-            return fam
+            return tagged.group(1) if tagged else fam
     if base == "k_conv_gather":  # <BN, WM, WN, DGRAD, VEC, ...>: the first five arguments, as profiler.py labels them
         t = re.search(r"k_conv_gather<([^>]*)>", name)
         return f"k_conv_gather<{', '.join(a.strip() for a in t.group(1).split(',')[:5])}>" if t else base
@@ -78,12 +83,14 @@ def _family(name: str, bf16s: bool) -> str:
     if base == "k_conv_first":  # <CIN, KS, WGRAD, BNAPPLY, SB>: the weight-gradient instances belong to snn_conv2d_wgrad
         t = re.search(r"k_conv_first<([^>]*)>", name)
         args = [a.strip() for a in t.group(1).split(",")] if t else []
-        return "k_conv_wgrad" if len(args) > 2 and args[2] == "true" else "k_conv_first<2, 3, false>"
+        return "k_conv_first<wgrad>" if len(args) > 2 and args[2] == "true" else "k_conv_first<2, 3, false>"
     if base in ("k_affine_neuron_fwd", "k_affine_neuron_bwd"):   # <NEURON, ...>: profiler.py labels the neuron
         t = re.search(base + r"<(\d+)", name)
         return f"{base}<{t.group(1)}>" if t else base
+    if base == "k_conv_wgrad_halo":
+        return "k_conv_wgrad_halo"   # the halo-resident 3x3 weight gradient (csrc/wgrad_halo.hip)
     if base.startswith("k_conv_wgrad"):
-        return "k_conv_wgrad"  # one snn_conv2d_wgrad call = one tile kernel (any variant) + its ordered reduce
+        return "k_conv_wgrad_pipe"   # the implicit GEMM, pipelined or exact fp32: every tile variant (+ its ordered reduce)
     return base
 
 
@@ -91,12 +98,21 @@ def aggregate(path, counter):
     """raw rocprofv3 counter csv -> {kernel name: [sum of the counter (KiB), launches]}"""
     per = collections.defaultdict(lambda: [0.0, 0])
     with open(path) as f:
-        for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
-            row = per[r["Kernel_Name"]]
-            row[0] += float(r["Counter_Value"])
-            row[1] += 1
+        rows = [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))   # program order (the passes run on ONE stream)
+    last_wgrad = None
+    for r in rows:
+        name = r["Kernel_Name"]
+        if counts_as_launch(name):
+            fam = _family(name, False)
+            if fam in WGRAD_FAMILIES:
+                last_wgrad = fam
+        elif last_wgrad is not None:
+            name = f"{name} [after {last_wgrad}]"   # a helper belongs to the call whose main kernel it followed
+        row = per[name]
+        row[0] += float(r["Counter_Value"])
+        row[1] += 1
     return per
 
 
