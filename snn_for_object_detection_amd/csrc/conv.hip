@@ -1456,6 +1456,47 @@ __global__ __launch_bounds__(kThreads) void k_wgrad_reduce4(const float* __restr
     *reinterpret_cast<f32x4*>(out) = s;
 }
 
+// The ordered reduction in ONE launch (round 4; the two-pass form above cost two latency-bound launches behind every one of
+// the ~38 weight gradients of a step): a block owns 256 consecutive elements (64 lanes x 16 bytes = 1 KiB runs per slab
+// row), its KG waves each sum a contiguous run of slab rows in row order, then wave 0 adds the KG partial sums in wave
+// order: fixed order, bitwise reproducible.
+template <int KG>
+__global__ __launch_bounds__(64 * KG) void k_wgrad_reduce_once(const float* __restrict__ src, int64_t n, int rows,
+                                                              float* __restrict__ dst, int accumulate) {
+    __shared__ f32x4 part[KG][64];
+    const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int per = (rows + KG - 1) / KG;
+    const int r0 = kg * per;
+    const int r1 = r0 + per < rows ? r0 + per : rows;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (e < n) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + (int64_t)r * n + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 1) * n + e);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 2) * n + e);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(src + (int64_t)(r + 3) * n + e);
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; r < r1; ++r) s = s + *reinterpret_cast<const f32x4*>(src + (int64_t)r * n + e);
+    }
+    if (KG > 1) {
+        part[kg][lane] = s;
+        __syncthreads();
+        if (kg == 0) {
+            s = part[0][lane];
+#pragma unroll
+            for (int g = 1; g < KG; ++g) s = s + part[g][lane];
+        }
+    }
+    if (kg == 0 && e < n) {
+        float* out = dst + e;
+        if (accumulate) s = *reinterpret_cast<const f32x4*>(out) + s;
+        *reinterpret_cast<f32x4*>(out) = s;
+    }
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
@@ -2515,6 +2556,27 @@ extern "C" int snn_conv2d_wgrad_kernel(int64_t N, int H, int W, int Cin, int Ho,
 
 // dw (+)= sum over the splitk workspace slabs, fixed order
 static int wgrad_reduce_slabs(float* workspace, float* dw, int64_t n, int splitk, int accumulate, hipStream_t st) {
+    if (n % 4 == 0 && aligned16(workspace) && aligned16(dw) && splitk > 1) {
+        // one launch when the rows a wave has to walk stay short: blocks of 256 elements, KG waves sharing the slab rows
+        const int64_t nb1 = snn_ceil_div(n, 256);
+        int kg = 1;
+        while (kg < 16 && nb1 * kg < 8 * (int64_t)snn_num_cu() && splitk / (2 * kg) >= 4) kg *= 2;
+        if (snn_ceil_div(splitk, kg) <= 48) {
+#define SNN_REDUCE_ONCE(KG_)                                                                                   \
+    hipLaunchKernelGGL((k_wgrad_reduce_once<KG_>), dim3((unsigned)nb1), dim3(64 * KG_), 0, st, workspace, n, splitk, dw, \
+                       accumulate)
+            switch (kg) {
+                case 1: SNN_REDUCE_ONCE(1); break;
+                case 2: SNN_REDUCE_ONCE(2); break;
+                case 4: SNN_REDUCE_ONCE(4); break;
+                case 8: SNN_REDUCE_ONCE(8); break;
+                default: SNN_REDUCE_ONCE(16); break;
+            }
+#undef SNN_REDUCE_ONCE
+            SNN_CHECK_LAUNCH("snn_conv2d_wgrad_reduce");
+            return 0;
+        }
+    }
     if (n % 4 == 0 && aligned16(workspace) && aligned16(dw) && splitk > 8) {
         const int64_t nb = snn_ceil_div(n / 4, kThreads);
         int64_t groups = snn_ceil_div(4 * snn_num_cu(), nb);   // ~4 blocks per CU in the first pass
