@@ -137,10 +137,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     constexpr int ES = SBF ? 2 : 4;             // bytes per activation element in HBM
     static_assert(!SBF || (!F16 && !BNAP && ABL == 0), "bf16 storage: bf16 MFMA, plain variant");
     constexpr int CF_BYTES = BNAP ? 3 * BN_NT * BN_CMAX * 4 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HPIECE + 2 * BTILE + CF_BYTES];   // ONE array
-    unsigned char* Aimg = smem;                        // [2 pieces][HCELLS][64 B]
-    unsigned char* Bimg = smem + 2 * HPIECE;           // [2 buffers][BTILE]
-    [[maybe_unused]] float* Cf = reinterpret_cast<float*>(smem + 2 * HPIECE + 2 * BTILE);   // [3 planes][BN_NT][Cin]
+    // cells the LDS halo image holds: a rectangle tile's halo is 6 x 34 = 204 cells (7 staging passes), not the 288 of the
+    // widest strip tile - 37 instead of 45 KiB of LDS for the 32-channel instance, i.e. FOUR instead of three blocks per CU
+    // on the 120x152 layers, whose blocks (54 MFMAs per wave) live on latency, not on the matrix pipe
+    constexpr int HC = RECT ? (RCELLS + 31) / 32 * 32 : HCELLS;
+    constexpr int HP = HC * 64;                        // bytes of one piece image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HP + 2 * BTILE + CF_BYTES];   // ONE array
+    unsigned char* Aimg = smem;                        // [2 pieces][HC][64 B]
+    unsigned char* Bimg = smem + 2 * HP;               // [2 buffers][BTILE]
+    [[maybe_unused]] float* Cf = reinterpret_cast<float*>(smem + 2 * HP + 2 * BTILE);   // [3 planes][BN_NT][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,13 +297,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     auto store_halo = [&]() {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
+            if constexpr (RECT)
+                if (p * 32 >= HC) continue;   // passes past the rectangle's halo (all their cells are out of range)
             if constexpr (SBF) {
                 *reinterpret_cast<u32x2*>(Aimg + awr[p]) = pf[p];
             } else {
                 u32x2 hi, lo;
                 split4<F16>(pf[p], hi, lo);
                 *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
-                *reinterpret_cast<u32x2*>(Aimg + HPIECE + awr[p]) = lo;
+                *reinterpret_cast<u32x2*>(Aimg + HP + awr[p]) = lo;
             }
         }
     };
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                     continue;
                 }
                 ah[i] = *reinterpret_cast<const bf16x8*>(Aimg + off);
-                if constexpr (!SBF) al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HPIECE + off);
+                if constexpr (!SBF) al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HP + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
