@@ -280,3 +280,32 @@ def test_stage_entry_lif_writes_no_spike_tensor_and_nothing_changes(S):
         HF.set_backward_precision(HF.DEFAULT_BACKWARD_PRECISION)
     assert "snn_conv1x1_spikes_fwd" not in [nm for nm, _ in calls2]
     assert float((y2 - y0).abs().max()) < 1e-4
+
+
+def test_three_sibling_branches_and_bf16_storage(S):
+    """Three branch-opening 1x1 convolutions (one of them followed by more layers inside a nested pass-through block is the
+    TinyYolo case; here: three plain ones of different widths) fuse as well; the same block in the bf16-storage mode runs the
+    fused path on bf16 tensors (own tolerances: one rounding per stored value)."""
+    HF = S.functional
+    cfg = [S.Conv(32, 3), S.Norm(), S.LIF(), S.Conv(64, 1), S.Dense([[S.Conv(32, 1)], [S.Conv(64, 1)], [S.Conv(32, 1)]]),
+           S.Conv(32, 1)]
+    fused, plain = _build(S, cfg, True), _build(S, cfg, False)
+    plain.load_state_dict(fused.state_dict())
+    plans = [m._siblings for m in fused.modules() if isinstance(m, S.BlockGen) and m._siblings]
+    assert plans == [[(0, 32, None), (32, 64, None), (96, 32, None)]]
+    x = synthetic_events(3, 2, 12, 20, p=0.3, seed=3).cuda()
+    probe = torch.randn(3, 2, 32, 12, 20, generator=torch.Generator().manual_seed(6)).cuda()
+    y1, gx1, g1 = _run(S, fused, x, True, probe)
+    y0, gx0, g0 = _run(S, plain, x, False, probe)
+    assert torch.equal(y1, y0) and rel_err(gx1, gx0) < 2e-5
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 5e-5, k
+    HF.set_activation_storage("bf16")
+    try:
+        yb, gxb, gb = _run(S, fused, x, True, probe)
+        yp, gxp, gp = _run(S, plain, x, False, probe)
+    finally:
+        HF.set_activation_storage("fp32")
+    assert rel_err(yb.float(), yp.float()) < 1e-2 and rel_err(yb.float(), y0) < 5e-2
+    for k in g0:
+        assert rel_err(gb[k], gp[k]) < 5e-2, k
