@@ -23,6 +23,10 @@ Pinning status
 * ``detect.py`` is PINNED: checked against outputs of the reference's own
   ``utils/{box,anchors,roi}.py`` executed in the build container; vectors and
   the generating script live in ``tests/golden/``.
+* ``net.py`` (executor, merges, state threading, taps, heads, the time loop, ``_loss``) is PINNED since round 4: bit for
+  bit against a run of the reference's own ``SODa`` / ``BlockGen`` / ``NeckGen`` / ``Head`` on a description without
+  spiking neurons (``tests/golden/executor.npz``); ``events.py`` (voxelisation, label selection, collate) likewise against
+  the reference's own ``utils/datasets.py`` methods (``tests/golden/events.npz``).
 * Conv2d / BatchNorm2d / pooling / losses are torch's own CPU kernels (the
   reference calls the same ``torch.nn`` modules), so they are the reference
   arithmetic by construction.

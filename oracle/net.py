@@ -22,6 +22,14 @@ description object drives the oracle and the product.
 Conv2d / BatchNorm2d / pools / Upsample / losses are torch's own CPU kernels - the
 very modules the reference instantiates.  LIF / LI come from ``oracle.neurons``
 (PARITY UNPINNED, see there).
+
+PINNED on a run of the reference itself since round 4: ``tests/golden/executor.npz`` holds what the reference's own
+``SODa`` (``__init__ / forward / _forward_impl / _loss``), ``BlockGen``, ``BackboneGen``, ``NeckGen``, ``Head`` / ``HeadGen``
+and layer modules produced for a description without spiking neurons (Conv, Norm, ReLU, SiLU, Tanh, Pool, Up, ConvLSTM,
+Pass, Return, Residual, Dense; ``tests/golden/make_golden.py::executor_golden``): ``SODaRef`` / ``BlockRef`` reproduce its
+state_dict keys, predictions, loss, every parameter gradient, the BatchNorm buffers and a block's ConvLSTM state tree
+BIT FOR BIT (``tests/test_oracle_pins.py::test_oracle_executor_heads_and_loss_match_the_reference_run``).  ConvLSTM, SLI and
+Synapse are pinned on their own fixtures as well; what stays unpinned in this file is nothing but the two norse cells.
 """
 
 import inspect

@@ -276,6 +276,165 @@ def events_golden():
     np.savez_compressed(os.path.join(OUT, "events.npz"), **out)
 
 
+def executor_golden():
+    """The reference's own EXECUTOR, heads and loss on a network description without spiking neurons: ``BlockGen`` /
+    ``BackboneGen`` / ``NeckGen`` / ``Head`` / ``HeadGen`` (``models/generator.py:82-538``), the layer generators and modules of
+    ``models/modules/{layer_gen,common,conv_lstm}.py``, ``AnchorGenerator``, and ``SODa.__init__ / forward / _forward_impl /
+    _loss`` (``models/soda.py:66-96,138-144,235-244,259-281``) - a real subclass of the reference's ``SODa`` whose three
+    description hooks use ``Conv, Norm, ReLU, SiLU, Tanh, Pool, Up, LSTM, Pass, Return, Residual, Dense`` only (everything but
+    the norse neurons), run forward over T steps (the ConvLSTM state threads through the reference's time loop), loss,
+    backward.  What stands in, and for what: ``lightning`` (``LightningModule`` = ``nn.Module`` + ``save_hyperparameters``),
+    ``torchmetrics.detection`` and ``utils.plotter`` (constructed / imported, never called here), norse (imported by the layer
+    files for classes this description never instantiates; ``norse.torch.utils.state._is_module_stateful`` is restated as
+    norse 1.1.0 defines it - "``forward`` has a parameter named ``state``" - and is the one piece of third-party logic this
+    fixture rests on).  ``models/generator.py`` uses two PEP 695 ``type`` aliases (:31-32) that python 3.10 cannot parse: the
+    file is compiled IN MEMORY with those two statements rewritten as plain assignments (they only feed annotations); every
+    other statement of every file runs as it is on disk.  Stored: the state_dict (keys = the reference's module-tree layout),
+    inputs, labels, the predictions of every prefix length, the loss, every parameter gradient, BatchNorm buffers afterwards."""
+    import inspect
+    import re
+
+    def standin(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        return m
+
+    class _LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *args, ignore=(), **kw):
+            frame = inspect.currentframe().f_back
+            names = [n for n in inspect.signature(type(self).__init__).parameters if n != "self"]
+            # (the subclass forwards **kwargs: take the base class's named arguments from the calling frame)
+            local = frame.f_locals
+            hp = {k: local[k] for k in inspect.signature(frame.f_globals["SODa"].__init__).parameters
+                  if k not in ("self", *ignore) and k in local}
+            self.hparams = types.SimpleNamespace(**hp)
+
+        def log(self, *a, **k):
+            pass
+
+    dummy = type("Dummy", (), {"__init__": lambda self, *a, **k: None})
+    norse_torch = standin("norse.torch", LIFCell=dummy, LICell=dummy)
+    mods = {
+        "lightning": standin("lightning", LightningModule=_LightningModule),
+        "torchmetrics": standin("torchmetrics"),
+        "torchmetrics.detection": standin("torchmetrics.detection", MeanAveragePrecision=dummy),
+        "norse": standin("norse", torch=norse_torch),
+        "norse.torch": norse_torch,
+        "norse.torch.module": standin("norse.torch.module"),
+        "norse.torch.module.snn": standin("norse.torch.module.snn", SNNCell=dummy, SNN=dummy,
+                                          _merge_states=lambda states: states),
+        "norse.torch.utils": standin("norse.torch.utils"),
+        "norse.torch.utils.state": standin(
+            "norse.torch.utils.state",
+            _is_module_stateful=lambda m: "state" in inspect.signature(m.forward).parameters),
+        "utils.plotter": standin("utils.plotter", Plotter=dummy),
+    }
+    mods["torchmetrics"].detection = mods["torchmetrics.detection"]
+    for pkg, sub in (("utils", "utils"), ("models", "models")):   # packages WITHOUT their __init__ (datasets / Lightning CLI)
+        m = standin(pkg)
+        m.__path__ = [os.path.join(REF, sub)]
+        mods[pkg] = m
+    for k in ("norse", "norse.torch", "norse.torch.module", "norse.torch.utils", "torchmetrics"):
+        mods[k].__path__ = []
+    touched = set(mods) | {"utils.anchors", "utils.box", "utils.roi", "models.modules", "models.modules.layer_gen",
+                           "models.modules.common", "models.modules.conv_lstm", "models.modules.sli",
+                           "models.modules.synapse", "models.generator", "models.soda"}
+    saved = {k: sys.modules.get(k) for k in touched}
+    sys.modules.update(mods)
+    try:
+        import importlib
+        gen = types.ModuleType("models.generator")
+        gen.__file__ = os.path.join(REF, "models", "generator.py")
+        src = open(gen.__file__).read()
+        src, n = re.subn(r"(?m)^type (ListGen|ListState) = ", r"\1 = ", src)
+        assert n == 2                                   # exactly the two PEP 695 statements, nothing else
+        src = src.replace("ListGen = List[LayerGen | ListGen]", "ListGen = List").replace(
+            "ListState = List[torch.Tensor | None | ListState]", "ListState = List")
+        sys.modules["models.generator"] = gen
+        exec(compile(src, gen.__file__, "exec"), gen.__dict__)
+        soda = importlib.import_module("models.soda")
+        L = importlib.import_module("models.modules")
+
+        class Net(soda.SODa):
+            def backbone_cfgs(self):
+                return [L.Conv(8, 3, 2), L.Norm(), L.ReLU(),
+                        L.Dense([[L.Conv(8, 1), L.Residual([[L.Conv(kernel_size=3), L.Norm(bias=True), L.Tanh()], [L.Pass()]])],
+                                 [L.Pool("S"), L.Up(), L.Conv(4, 1)]]),
+                        L.Conv(16, 1)]
+
+            def neck_cfgs(self):
+                return [L.Conv(16, 3, 2), L.Norm(), L.Tanh(), L.LSTM(), L.Return(),
+                        L.Conv(24, 3, 2), L.Norm(), L.SiLU(), L.Pool("M", 1, 1), L.Return()]
+
+            def head_cfgs(self, box_out, cls_out):
+                return [[L.Conv(kernel_size=1), L.Norm(), L.Tanh()], [L.Conv(box_out, 1)], [L.Conv(cls_out, 1)]]
+
+        torch.manual_seed(11)
+        net = Net(num_classes=3, time_window=0)
+        net.train()
+        g = torch.Generator().manual_seed(12)
+        T, B, H, W = 3, 2, 24, 32
+        X = (torch.rand(T, B, 2, H, W, generator=g) < 0.2).float()
+        labels = random_labels(g, batch=B, n_boxes=2, n_classes=3, pad_rows=1)
+        out = {"X": X.numpy(), "labels": labels.numpy(), "num_classes": 3,
+               "loss_ratio": net.hparams.loss_ratio, "iou_threshold": net.hparams.iou_threshold}
+        sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        out["state_keys"] = np.array(list(sd0.keys()))
+        for k, v in sd0.items():
+            out["init/" + k] = v.numpy()
+        anchors, cls_preds, bbox_preds = net(X)                       # soda.py:138-144: time loop, last step's predictions
+        loss = net._loss((anchors, cls_preds, bbox_preds), labels)   # soda.py:259-281
+        loss.backward()
+        out.update(anchors=anchors.detach().numpy(), cls_preds=cls_preds.detach().numpy(),
+                   bbox_preds=bbox_preds.detach().numpy(), loss=float(loss.detach()))
+        out["no_grad"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                out["grad/" + k] = p.grad.numpy()
+        for k, v in net.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                out["after/" + k] = v.detach().numpy()
+        # one block on its own with an explicit state tree: the executor's state threading (generator.py:169-198)
+        torch.manual_seed(13)
+        blk = gen.BlockGen(4, [L.Conv(6, 3), L.Norm(), L.Tanh(), L.Dense([[L.LSTM(5)], [L.Pass()], [L.Conv(3, 1), L.SiLU()]]),
+                               L.Residual([[L.Conv(kernel_size=1)], [L.LSTM()]])])
+        blk.eval()
+        xs = torch.randn(4, 2, 4, 6, 7, generator=g)
+        state, ys = None, []
+        with torch.no_grad():
+            for t in range(4):
+                y, state = blk(xs[t], state)
+                ys.append(y)
+        out.update(blk_x=xs.numpy(), blk_y=torch.stack(ys).numpy(), blk_out_channels=blk.out_channels,
+                   blk_state_mask=np.array(json_dumps(blk.branch_state)))
+        for k, v in blk.state_dict().items():
+            out["blk/" + k] = v.detach().numpy()
+        flat = []
+
+        def walk(s, path):
+            if isinstance(s, (list, tuple)):
+                for i, e in enumerate(s):
+                    walk(e, path + [i])
+            elif isinstance(s, torch.Tensor):
+                flat.append((".".join(map(str, path)), s))
+        walk(state, [])
+        out["blk_state_paths"] = np.array([p for p, _ in flat])
+        for p_, t_ in flat:
+            out["blk_state/" + p_] = t_.numpy()
+        np.savez_compressed(os.path.join(OUT, "executor.npz"), **out)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def json_dumps(obj):
+    import json
+    return json.dumps(obj)
+
+
 def tiny_yolo_description():
     """Execute ``models/tiny_yolo.py`` with recording stand-ins for ``models.soda.SODa`` / ``models.generator`` /
     ``models.modules`` (the real ones need Lightning, norse and python >= 3.12): the file only BUILDS nested lists of
@@ -409,6 +568,7 @@ def main():
     convlstm_golden(gen)
     sli_synapse_golden(gen)
     events_golden()
+    executor_golden()
     tiny_yolo_description()
     print("golden vectors written to", OUT)
 

@@ -8,7 +8,7 @@ threshold (SURVEY section 7 "spike-flip sensitivity").
 import pytest
 import torch
 
-from tests.util import make_pair, rel_err, synthetic_events, synthetic_labels
+from tests.util import executor_net, make_pair, rel_err, synthetic_events, synthetic_labels
 
 pytestmark = pytest.mark.gpu
 
@@ -245,3 +245,43 @@ def test_heads_on_auxiliary_streams_are_bit_identical(S):
     for a, b, c in zip(plain, one, two):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+def test_generated_net_without_neurons_matches_the_reference_run(S, golden_dir):
+    """The HIP path against the REFERENCE's own run (``tests/golden/executor.npz``: the reference's ``SODa`` / ``BlockGen`` /
+    ``NeckGen`` / ``Head`` / ``_loss`` executed on a description of Conv / Norm / ReLU / SiLU / Tanh / Pool / Up / ConvLSTM /
+    Residual / Dense / Return layers, ``make_golden.py::executor_golden``) - no oracle in between: same state_dict keys,
+    predictions of the last step within 1e-4, loss 1e-4, every gradient 1e-3 (L2, relative), BatchNorm buffers 1e-5."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "executor.npz"))
+    keys = [str(k) for k in z["state_keys"]]
+    torch.manual_seed(0)
+    model = executor_net(S)(num_classes=int(z["num_classes"]), time_window=0, loss_ratio=float(z["loss_ratio"]),
+                            iou_threshold=float(z["iou_threshold"]))
+    assert list(model.state_dict().keys()) == keys
+    model.load_state_dict({k: torch.from_numpy(z["init/" + k]) for k in keys})
+    model = model.cuda().train()
+    X, labels = torch.from_numpy(z["X"]).cuda(), torch.from_numpy(z["labels"]).cuda()
+    anchors, cls_preds, bbox_preds = model(X)
+    loss = model._loss((anchors, cls_preds, bbox_preds), labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    S.functional.wgrad_stream_sync()
+    torch.cuda.synchronize()
+    assert torch.allclose(anchors.cpu(), torch.from_numpy(z["anchors"]), rtol=0, atol=1e-6)
+    assert rel_err(cls_preds, torch.from_numpy(z["cls_preds"])) < 1e-4
+    assert rel_err(bbox_preds, torch.from_numpy(z["bbox_preds"])) < 1e-4
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    no_grad = {str(k) for k in z["no_grad"]}
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k in no_grad:
+            continue
+        worst = max(worst, rel_err(p.grad, torch.from_numpy(z["grad/" + k])))
+    assert worst < 1e-3, worst
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v, torch.from_numpy(z["after/" + k])) < 1e-5, k
+        elif "num_batches" in k:
+            assert int(v) == int(z["after/" + k]), k

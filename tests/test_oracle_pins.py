@@ -15,6 +15,7 @@ import torch
 
 import snn_for_object_detection_amd as S
 from oracle import net as ON
+from tests.util import executor_block_cfg, executor_net
 
 
 def test_oracle_convlstm_matches_reference_vectors(golden_dir):
@@ -171,3 +172,55 @@ def test_oracle_event_voxelisation_matches_reference_vectors(golden_dir):
     samples = [(z[f"stack_features_{b}"], z[f"stack_labels_{b}"]) for b in range(3)]
     feats, targets = OE.stack_batch(samples)
     assert np.array_equal(feats, z["stack_out_features"]) and np.array_equal(targets, z["stack_out_targets"])
+
+
+# ------------------------------------------------------------------------------------------- executor, heads, loss
+def test_oracle_executor_heads_and_loss_match_the_reference_run(golden_dir):
+    """``oracle.net`` (BlockRef / SODaRef: executor, merges, state threading, taps, heads, flatten / concat, the time loop and
+    ``_loss``) against ``tests/golden/executor.npz`` - what the REFERENCE's own ``BlockGen / BackboneGen / NeckGen / Head /
+    SODa.forward / SODa._loss`` produced for a description without spiking neurons (``make_golden.py::executor_golden``: every
+    file as on disk but two PEP 695 alias statements of ``models/generator.py``).  Same module-tree keys, and - both sides are
+    torch CPU kernels behind the same sequence of calls - the same bits: predictions, loss, every gradient, the BatchNorm
+    buffers, the ConvLSTM state tree of a block threaded through four steps."""
+    z = np.load(os.path.join(golden_dir, "executor.npz"))
+    keys = [str(k) for k in z["state_keys"]]
+    torch.manual_seed(0)
+    desc = executor_net(S)(num_classes=int(z["num_classes"]), time_window=0)
+    ref = ON.SODaRef(desc, int(z["num_classes"]), loss_ratio=float(z["loss_ratio"]), time_window=0,
+                     iou_threshold=float(z["iou_threshold"]))
+    assert list(ref.state_dict().keys()) == keys and list(desc.state_dict().keys()) == keys
+    ref.load_state_dict({k: torch.from_numpy(z["init/" + k]) for k in keys})
+    ref.train()
+    X, labels = torch.from_numpy(z["X"]), torch.from_numpy(z["labels"])
+    anchors, cls_preds, bbox_preds = ref(X)
+    loss = ref._loss((anchors, cls_preds, bbox_preds), labels)
+    loss.backward()
+    assert torch.equal(anchors, torch.from_numpy(z["anchors"]))
+    assert torch.equal(cls_preds.detach(), torch.from_numpy(z["cls_preds"]))
+    assert torch.equal(bbox_preds.detach(), torch.from_numpy(z["bbox_preds"]))
+    assert float(loss.detach()) == float(z["loss"])
+    no_grad = {str(k) for k in z["no_grad"]}
+    for k, p in ref.named_parameters():
+        if k in no_grad:
+            continue
+        assert torch.equal(p.grad, torch.from_numpy(z["grad/" + k])), k
+    for k, v in ref.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            assert torch.equal(v, torch.from_numpy(z["after/" + k])), k
+    # one block with an explicit state tree
+    blk = ON.BlockRef(4, executor_block_cfg(S)).eval()
+    assert blk.out_channels == int(z["blk_out_channels"])
+    blk.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("blk/")})
+    assert json.dumps(blk.branch_state) == str(z["blk_state_mask"])
+    xs = torch.from_numpy(z["blk_x"])
+    state, ys = None, []
+    with torch.no_grad():
+        for t in range(xs.shape[0]):
+            y, state = blk(xs[t], state)
+            ys.append(y)
+    assert torch.equal(torch.stack(ys), torch.from_numpy(z["blk_y"]))
+    for path in z["blk_state_paths"]:
+        node = state
+        for i in str(path).split("."):
+            node = node[int(i)]
+        assert torch.equal(node, torch.from_numpy(z["blk_state/" + str(path)])), path

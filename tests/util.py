@@ -43,3 +43,28 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 def max_rel(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-6) -> float:
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float(((a - b).abs() / (b.abs().max() + floor)).max())
+
+
+def executor_net(pkg):
+    """The description of tests/golden/make_golden.py::executor_golden, written with THIS package's layer generators."""
+    L = pkg
+
+    class Net(pkg.SODa):
+        def backbone_cfgs(self):
+            return [L.Conv(8, 3, 2), L.Norm(), L.ReLU(),
+                    L.Dense([[L.Conv(8, 1), L.Residual([[L.Conv(kernel_size=3), L.Norm(bias=True), L.Tanh()], [L.Pass()]])],
+                             [L.Pool("S"), L.Up(), L.Conv(4, 1)]]),
+                    L.Conv(16, 1)]
+
+        def neck_cfgs(self):
+            return [L.Conv(16, 3, 2), L.Norm(), L.Tanh(), L.LSTM(), L.Return(),
+                    L.Conv(24, 3, 2), L.Norm(), L.SiLU(), L.Pool("M", 1, 1), L.Return()]
+
+        def head_cfgs(self, box_out, cls_out):
+            return [[L.Conv(kernel_size=1), L.Norm(), L.Tanh()], [L.Conv(box_out, 1)], [L.Conv(cls_out, 1)]]
+    return Net
+
+
+def executor_block_cfg(L):
+    return [L.Conv(6, 3), L.Norm(), L.Tanh(), L.Dense([[L.LSTM(5)], [L.Pass()], [L.Conv(3, 1), L.SiLU()]]),
+            L.Residual([[L.Conv(kernel_size=1)], [L.LSTM()]])]
