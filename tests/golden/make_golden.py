@@ -394,6 +394,25 @@ def executor_golden():
         for k, v in net.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 out["after/" + k] = v.detach().numpy()
+        # streaming inference (soda.py:202-233): eval mode, one frame at a time, the detector state threaded by the caller
+        net.eval()
+        st = None
+        with torch.no_grad():
+            for t in range(T):
+                det, st = net.predict(X[t, 0], st)
+                out[f"predict_{t}"] = det.numpy()
+        pflat = []
+
+        def pwalk(s_, path):
+            if isinstance(s_, (list, tuple)):
+                for i_, e_ in enumerate(s_):
+                    pwalk(e_, path + [i_])
+            elif isinstance(s_, torch.Tensor):
+                pflat.append((".".join(map(str, path)), s_))
+        pwalk(st, [])
+        out["predict_state_paths"] = np.array([p_ for p_, _ in pflat])
+        for p_, t_ in pflat:
+            out["predict_state/" + p_] = t_.numpy()
         # one block on its own with an explicit state tree: the executor's state threading (generator.py:169-198)
         torch.manual_seed(13)
         blk = gen.BlockGen(4, [L.Conv(6, 3), L.Norm(), L.Tanh(), L.Dense([[L.LSTM(5)], [L.Pass()], [L.Conv(3, 1), L.SiLU()]]),

@@ -285,3 +285,16 @@ def test_generated_net_without_neurons_matches_the_reference_run(S, golden_dir):
             assert rel_err(v, torch.from_numpy(z["after/" + k])) < 1e-5, k
         elif "num_batches" in k:
             assert int(v) == int(z["after/" + k]), k
+    # streaming inference (soda.py:202-233) through the device decode / NMS kernels: the reference's detections, frame by frame
+    model.eval()
+    st = None
+    with torch.no_grad():
+        for t in range(X.shape[0]):
+            det, st = model.predict(X[t, 0], st)
+            want = torch.from_numpy(z[f"predict_{t}"])
+            assert det.shape == want.shape, (t, det.shape, want.shape)
+            # same set of detections (class, box); the reference orders equal confidences with an unstable sort
+            got = det.cpu()
+            key = lambda d: sorted(map(tuple, torch.cat([d[:, :1], (d[:, 2:] * 1e4).round()], dim=1).tolist()))
+            assert key(got) == key(want), t
+            assert torch.allclose(got[:, 1].sort().values, want[:, 1].sort().values, atol=1e-5)

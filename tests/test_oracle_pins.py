@@ -207,6 +207,18 @@ def test_oracle_executor_heads_and_loss_match_the_reference_run(golden_dir):
     for k, v in ref.state_dict().items():
         if "running_" in k or "num_batches" in k:
             assert torch.equal(v, torch.from_numpy(z["after/" + k])), k
+    # streaming inference (soda.py:202-233): eval mode, frame by frame, state threaded by the caller - same rows, same order
+    ref.eval()
+    st = None
+    with torch.no_grad():
+        for t in range(X.shape[0]):
+            det, st = ref.predict(X[t, 0], st)
+            assert torch.equal(det, torch.from_numpy(z[f"predict_{t}"])), t
+    for path in z["predict_state_paths"]:
+        node = st
+        for i in str(path).split("."):
+            node = node[int(i)]
+        assert torch.equal(node, torch.from_numpy(z["predict_state/" + str(path)])), path
     # one block with an explicit state tree
     blk = ON.BlockRef(4, executor_block_cfg(S)).eval()
     assert blk.out_channels == int(z["blk_out_channels"])
