@@ -394,6 +394,19 @@ def executor_golden():
         for k, v in net.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 out["after/" + k] = v.detach().numpy()
+        # training_step with the reference's default time_window = 16 (soda.py:146-158, 246-257): a random prefix of the
+        # sequence is dropped, the draw taken from torch's global generator
+        torch.manual_seed(21)
+        net2 = Net(num_classes=3)                        # time_window = 16, the default
+        net2.load_state_dict(sd0)
+        net2.train()
+        Xl = (torch.rand(18, B, 2, H, W, generator=g) < 0.2).float()
+        torch.manual_seed(5)
+        loss2 = net2.training_step((Xl, labels), 0)
+        loss2.backward()
+        out.update(ts_X=Xl.numpy(), ts_seed=5, ts_time_window=net2.hparams.time_window, ts_loss=float(loss2.detach()),
+                   ts_grad_first=net2.base_net.net.net[0][0].weight.grad.numpy(),
+                   ts_nbt=int(net2.base_net.net.net[0][1].num_batches_tracked))   # = frames that were actually run
         # streaming inference (soda.py:202-233): eval mode, one frame at a time, the detector state threaded by the caller
         net.eval()
         st = None

@@ -285,6 +285,20 @@ def test_generated_net_without_neurons_matches_the_reference_run(S, golden_dir):
             assert rel_err(v, torch.from_numpy(z["after/" + k])) < 1e-5, k
         elif "num_batches" in k:
             assert int(v) == int(z["after/" + k]), k
+    # training_step with the reference's default time_window = 16: the same draw, the same dropped prefix (soda.py:146-158)
+    m2 = executor_net(S)(num_classes=int(z["num_classes"]), loss_ratio=float(z["loss_ratio"]),
+                         iou_threshold=float(z["iou_threshold"]))
+    assert m2.hparams.time_window == int(z["ts_time_window"]) == 16
+    m2.load_state_dict({k: torch.from_numpy(z["init/" + k]) for k in keys})
+    m2 = m2.cuda().train()
+    torch.manual_seed(int(z["ts_seed"]))
+    loss2 = m2.training_step((torch.from_numpy(z["ts_X"]).cuda(), labels))
+    loss2.backward()
+    S.functional.wgrad_stream_sync()
+    torch.cuda.synchronize()
+    assert abs(float(loss2.detach()) - float(z["ts_loss"])) < 1e-4 * abs(float(z["ts_loss"]))
+    assert int(m2.base_net.net.net[0][1].num_batches_tracked) == int(z["ts_nbt"])      # frames actually run
+    assert rel_err(m2.base_net.net.net[0][0].weight.grad, torch.from_numpy(z["ts_grad_first"])) < 1e-3
     # streaming inference (soda.py:202-233) through the device decode / NMS kernels: the reference's detections, frame by frame
     model.eval()
     st = None

@@ -207,6 +207,17 @@ def test_oracle_executor_heads_and_loss_match_the_reference_run(golden_dir):
     for k, v in ref.state_dict().items():
         if "running_" in k or "num_batches" in k:
             assert torch.equal(v, torch.from_numpy(z["after/" + k])), k
+    # training_step with time_window = 16: the same draw from the global generator, the same dropped prefix, the same loss
+    ref2 = ON.SODaRef(desc, int(z["num_classes"]), loss_ratio=float(z["loss_ratio"]), time_window=int(z["ts_time_window"]),
+                      iou_threshold=float(z["iou_threshold"]))
+    ref2.load_state_dict({k: torch.from_numpy(z["init/" + k]) for k in keys})
+    ref2.train()
+    torch.manual_seed(int(z["ts_seed"]))
+    loss2 = ref2.training_step((torch.from_numpy(z["ts_X"]), labels))
+    loss2.backward()
+    assert float(loss2.detach()) == float(z["ts_loss"])
+    assert int(ref2.base_net.net.net[0][1].num_batches_tracked) == int(z["ts_nbt"]) < z["ts_X"].shape[0]
+    assert torch.equal(ref2.base_net.net.net[0][0].weight.grad, torch.from_numpy(z["ts_grad_first"]))
     # streaming inference (soda.py:202-233): eval mode, frame by frame, state threaded by the caller - same rows, same order
     ref.eval()
     st = None
