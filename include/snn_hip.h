@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 9
+#define SNN_ABI_VERSION 10
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -85,11 +85,18 @@ enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even 
                                         out, addend, vdec; bwd: g_out, state, y, gx - are bf16 (pointers passed as float*,
                                         strides in elements); state (v, i), alpha / beta and the sums stay fp32.
                                         NONE / LIF / LI / LI+Tanh, C and strides multiples of 4 */
-       SNN_SCAN_SPIKES_FROM_VDEC = 8 /* fwd, Norm -> LIF without a shortcut whose potentials are saved (vdec != NULL): write
+       SNN_SCAN_SPIKES_FROM_VDEC = 8,/* fwd, Norm -> LIF without a shortcut whose potentials are saved (vdec != NULL): write
                                         NO output tensor (out must be NULL) - the saved pre-reset potentials already hold
                                         the spikes, z = (v_dec > v_th), and the consumer forms them while it reads them
                                         (snn_conv1x1_spikes_fwd / _wgrad): 4 of the 12 bytes the scan moves per
-                                        neuron-timestep never exist.  fp32 tensors, C and ldy multiples of 4 */ };
+                                        neuron-timestep never exist.  fp32 tensors, C and ldy multiples of 4 */
+       SNN_SCAN_SUMS_FROM_STATE = 16 /* bwd, LIF from the initial state with `sums` wanted: y is NOT read (NULL allowed).
+                                        The BatchNorm statistic the scan needs y for, sum(gx * y), is replaced by
+                                        sum(gx * x) with the neuron's input x[t] = alpha*y[t] + beta rebuilt from the saved
+                                        potentials (vd[t], vd[t-1], vd[t-2] and the reset rule determine x[t] to fp32
+                                        rounding): 4 of the 16 bytes per neuron-timestep are never read.  The sums must
+                                        then go through snn_bn_bwd_finalize_from_state.  Covered cases:
+                                        snn_affine_neuron_bwd_sums_from_state(); g_v0 / g_i0 must be NULL */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };
@@ -327,6 +334,10 @@ int snn_affine_neuron_fwd(int neuron, const float* y, int64_t ldy,
  * apply_scale != 0: gx is multiplied by alpha[t,c] before it is written (eval-mode BN: dy = alpha*gx).
  * flags: 0, SNN_SCAN_WIDE_ADDRESSING, SNN_SCAN_LAST_STEP_ONLY (or both). */
 size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C);
+/* 1 when snn_affine_neuron_bwd(flags | SNN_SCAN_SUMS_FROM_STATE) covers the call (LIF, the ordered-sums plan of the shape,
+ * 32-bit buffer addressing, fp32 tensors, all T gradients, c_mem in [1/64, 1]) */
+int snn_affine_neuron_bwd_sums_from_state(int neuron, int T, int64_t M, int C, int64_t ldg, const snn_neuron_params* p,
+                                          int flags);
 int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state,
                           const float* y, int64_t ldy, const float* g_vT, const float* g_iT,
                           const float* alpha, const float* beta, int apply_scale,
@@ -357,10 +368,23 @@ int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C,
                         const float* gamma, const float* mean, const float* invstd,
                         float* coefA, float* coefB, float* coefC,
                         float* dgamma, float* dbias, int accumulate, void* stream);
+/* The same for sums of a scan that ran with SNN_SCAN_SUMS_FROM_STATE: sum(gx*y) = mean*sum(gx) + (sum(gx*x) - bias*sum(gx))
+ * / (gamma*invstd) (bias NULL = 0, gamma NULL = 1), then as above.  A channel whose gamma is exactly 0 has no xhat left in x: its sum(gx*y) is formed
+ * from gx[T][M][C] and y[T][M][ldy] inside this call (one block per such channel: slow, exact, rare). */
+int snn_bn_bwd_finalize_from_state(double* sums, int T, int64_t M, int C,
+                                   const float* gamma, const float* bias, const float* mean, const float* invstd,
+                                   const float* gx, const float* y, int64_t ldy,
+                                   float* coefA, float* coefB, float* coefC,
+                                   float* dgamma, float* dbias, int accumulate, void* stream);
 /* The same in two steps for SyncBatchNorm: raw[T][C][2] = (sum gx, sum gx*y) of this rank; the caller
  * all-reduces a copy; coefficients come from the global sums over M_total pixels while dgamma / dbias use
  * the rank-local sums (DDP averages them afterwards).  param_sums: T*C*2 doubles of scratch. */
 int snn_bn_bwd_reduce(const double* sums, int T, int64_t M, int C, double* raw, void* stream);
+/* ... for sums of a scan that ran with SNN_SCAN_SUMS_FROM_STATE: raw receives (sum gx, sum gx*y) all the same (converted
+ * with this rank's view of gamma / bias / mean / invstd, which SyncBatchNorm keeps equal on every rank) */
+int snn_bn_bwd_reduce_from_state(const double* sums, int T, int64_t M, int C, const float* gamma, const float* bias,
+                                 const float* mean, const float* invstd, const float* gx, const float* y, int64_t ldy,
+                                 double* raw, void* stream);
 int snn_bn_bwd_coef(const double* raw, const double* raw_local, double* param_sums, int T, int64_t M_total, int C,
                     const float* gamma, const float* mean, const float* invstd,
                     float* coefA, float* coefB, float* coefC,

@@ -15,9 +15,9 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
-SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE, SCAN_SPIKES_FROM_VDEC = 1, 2, 4, 8
+SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE, SCAN_SPIKES_FROM_VDEC, SCAN_SUMS_FROM_STATE = 1, 2, 4, 8, 16
 
 
 class NeuronParams(Structure):
@@ -81,6 +81,9 @@ SIGNATURES = {
     "snn_affine_neuron_bwd": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _L, _I,
                                       POINTER(NeuronParams), _I, _P]),
     "snn_bn_bwd_finalize": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "snn_bn_bwd_finalize_from_state": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P]),
+    "snn_bn_bwd_reduce_from_state": (c_int, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "snn_affine_neuron_bwd_sums_from_state": (c_int, [_I, _I, _L, _I, _L, POINTER(NeuronParams), _I]),
     "snn_bn_bwd_apply": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
     "snn_bn_bwd_apply_bf16": (c_int, [_P, _P, _L, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
     "snn_bn_stats_bf16": (c_int, [_P, _L, _I, _L, _I, _P, _P]),

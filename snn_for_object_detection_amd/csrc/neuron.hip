@@ -629,8 +629,16 @@ static BwdPlan bwd_plan(int T, int64_t M, int C, bool with_sums) {
 // every pixel (vmcnt(0)): the prefetch bought nothing and the kernel ran at 3.9 TB/s with the texture addresser 16 %
 // busy.  Host-checked: one timestep of every tensor is < 2 GiB.
 // SB (SNN_SCAN_BF16_STORAGE): g_out, state, y and gx are bf16 tensors (pointers passed as float*, strides in elements).
-template <int NEURON, int VEC, int MODE, bool BUF, int NP, bool SB = false>
-__global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
+// YF (SNN_SCAN_SUMS_FROM_STATE; LIF, MODE 1, BUF, fp32 tensors, initial state (v_leak, 0)): y is NOT read.  The only use the
+// scan has for y is the BatchNorm statistic sum(gx * y), and the neuron's input x[t] = alpha*y[t] + beta - which carries the
+// same information, sum(gx * x) = alpha * sum(gx * y) + beta * sum(gx) - can be rebuilt from the saved potentials the scan
+// reads anyway: with v[t-1] = (vd[t-1] > v_th ? v_reset : vd[t-1]) the forward step vd[t] = v[t-1] + c_mem*((v_leak - v[t-1])
+// + i'[t]) gives i'[t], and x[t] = i'[t] - (i'[t-1] + c_syn*i'[t-1]).  Walking backwards, step t holds vd[t] and has kept
+// vd[t+1]: it forms i'[t+1], with the i'[t+2] of the step before x[t+2], and adds gx[t+2] * x[t+2] (kept two steps) to the
+// slab row of step t+2; x[1] and x[0] follow after the loop from the initial state.  4 of the 16 bytes per neuron-timestep
+// are never read; the second value of a sums pair is then sum(gx * x) (snn_bn_bwd_finalize_from_state converts).
+template <int NEURON, int VEC, int MODE, bool BUF, int NP, bool SB = false, bool YF = false>
+__global__ __launch_bounds__(kThreads, YF ? 2 : 1) void k_affine_neuron_bwd(
     const float* __restrict__ g_out, int64_t ldg, const float* __restrict__ state, const float* __restrict__ y,
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
     const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
@@ -657,8 +665,10 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
         for (int k = tid; k < n; k += kThreads) red[k] = 0.0f;
         __syncthreads();
     }
+    static_assert(!YF || (NEURON == SNN_NEURON_LIF && MODE == 1 && BUF && VEC == 4 && !SB), "sums from the saved state: LIF, ordered sums");
     const float one_m_cmem = 1.0f - p.c_mem;
     const float one_p_csyn = 1.0f + p.c_syn;
+    [[maybe_unused]] const float inv_cmem = 1.0f / p.c_mem;
     const int64_t rows = (M + P - 1) / P;
     const int64_t rpb = (rows + gridDim.x - 1) / gridDim.x;  // pixel rows per block (see bwd_plan)
     const int64_t row_lo = (int64_t)blockIdx.x * rpb;
@@ -667,12 +677,19 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
         int64_t mq[NP];
         bool ok[NP];
         V gv[NP], gi[NP];
+        // YF: what a step keeps for the statistic of two steps later - vd[t+1], i'[t+2], gx[t+1], gx[t+2]
+        [[maybe_unused]] V yf_vd1[YF ? NP : 1], yf_in2[YF ? NP : 1], yf_g1[YF ? NP : 1], yf_g2[YF ? NP : 1];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             mq[q] = (rb + q) * P + ps;
             ok[q] = lane_ok && rb + q < row_hi && mq[q] < M;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) lane<VEC>(gv[q], j) = lane<VEC>(gi[q], j) = 0.0f;
+            if constexpr (YF) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    lane<VEC>(yf_vd1[q], j) = lane<VEC>(yf_in2[q], j) = lane<VEC>(yf_g1[q], j) = lane<VEC>(yf_g2[q], j) = 0.0f;
+            }
             if (NEURON != SNN_NEURON_NONE && ok[q]) {
                 if (g_vT) gv[q] = Vec<VEC>::load(g_vT + mq[q] * C + c);
                 if (g_iT) gi[q] = Vec<VEC>::load(g_iT + mq[q] * C + c);
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     for (int q = 0; q < NP; ++q)
                         st[q] = bload_last(rs, os[q]);
                 }
-                if (MODE != 0 || kNeedsX) {
+                if ((MODE != 0 && !YF) || kNeedsX) {
                     const __amdgpu_buffer_rsrc_t ry = slab(y, t, ldy);
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
@@ -788,7 +805,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 V go_q = widen(go_r[q]);
                 [[maybe_unused]] V st_q, yv_q;
                 if (kNeedsState) st_q = widen(st_r[q]);
-                if (MODE != 0) yv_q = widen(yv_r[q]);
+                if (MODE != 0 && !YF) yv_q = widen(yv_r[q]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     float goj = lane<VEC>(go_q, j);
@@ -809,6 +826,16 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                         lane<VEC>(gv[q], j) = g_vd * one_m_cmem;
                         lane<VEC>(gi[q], j) = g_in;
                         lane<VEC>(g, j) = g_in;
+                        if constexpr (YF) {   // x[t+2] from vd[t+2], vd[t+1], vd[t] (zero gradient slots until t+2 exists)
+                            const float vprev = (u > 0.0f) ? p.v_reset : vd;                       // v[t]
+                            const float in1 = (lane<VEC>(yf_vd1[q], j) - vprev) * inv_cmem - (p.v_leak - vprev);   // i'[t+1]
+                            const float x2 = lane<VEC>(yf_in2[q], j) - (in1 + p.c_syn * in1);
+                            s2[j] += lane<VEC>(yf_g2[q], j) * x2;
+                            lane<VEC>(yf_in2[q], j) = in1;
+                            lane<VEC>(yf_vd1[q], j) = vd;
+                            lane<VEC>(yf_g2[q], j) = lane<VEC>(yf_g1[q], j);
+                            lane<VEC>(yf_g1[q], j) = g_in;
+                        }
                     } else if (NEURON == SNN_NEURON_SLI) {
                         const float v_old = lane<VEC>(st_q, j);
                         const float xj = lane<VEC>(xa[q], j);
@@ -845,7 +872,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                     }
                     if (MODE != 0) {
                         s1[j] += lane<VEC>(g, j);
-                        s2[j] += lane<VEC>(g, j) * lane<VEC>(yv_q, j);
+                        if constexpr (!YF) s2[j] += lane<VEC>(g, j) * lane<VEC>(yv_q, j);
                     }
                 }
                 if (apply_scale) {
@@ -869,10 +896,19 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 if (!BWD_ABL(1)) wave_sum_channels<VEC>(s1, s2, cvb);
                 if (wave_sum_owner(tid & 63, cvb) && lane_ok && !BWD_ABL(0)) {
                     float* r = red + (((int64_t)wave * T + t) * cb + cgl * VEC) * 2;
+                    if constexpr (YF) {   // s2 belongs to step t + 2
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        r[j * 2 + 0] += s1[j];
-                        r[j * 2 + 1] += s2[j];
+                        for (int j = 0; j < VEC; ++j) r[j * 2 + 0] += s1[j];
+                        if (t + 2 < T) {
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) r[(2 * cb + j) * 2 + 1] += s2[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            r[j * 2 + 0] += s1[j];
+                            r[j * 2 + 1] += s2[j];
+                        }
                     }
                 }
             } else if (MODE == 2) {
@@ -926,6 +962,33 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_bwd(
                 if (t >= 1) {
                     if (t >= 2) fetch(t - 2, goA, stA, yvA, scA);
                     process(t - 1, goB, stB, yvB, scB);
+                }
+            }
+        }
+        if constexpr (YF) {
+            // the two statistics the loop still owes: x[1] = i'[1] - i[0] and x[0] = i'[0] - 0, i'[0] from the initial
+            // state v = v_leak (after the loop: vd1 = vd[0], in2 = i'[1], g1 = gx[0], g2 = gx[1])
+            float sa[VEC], sb0[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sa[j] = sb0[j] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float in0 = (lane<VEC>(yf_vd1[q], j) - p.v_leak) * inv_cmem;   // - (v_leak - v_leak)
+                    const float x1 = lane<VEC>(yf_in2[q], j) - (in0 + p.c_syn * in0);
+                    sa[j] += lane<VEC>(yf_g2[q], j) * x1;
+                    sb0[j] += lane<VEC>(yf_g1[q], j) * in0;
+                }
+            }
+            wave_sum_channels<VEC>(sa, sb0, cvb);
+            if (wave_sum_owner(tid & 63, cvb) && lane_ok) {
+                float* r = red + (((int64_t)wave * T) * cb + cgl * VEC) * 2;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) r[j * 2 + 1] += sb0[j];
+                if (T >= 2) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) r[(cb + j) * 2 + 1] += sa[j];
                 }
             }
         }
@@ -1174,12 +1237,26 @@ __global__ __launch_bounds__(kThreads) void k_lif_bwd_ckpt(
 
 // reduce block partials -> raw[t][c] = (sum gx, sum gx*y).  32 lanes per (t,c): lane k sums blocks k, k+32, ...
 // then a fixed xor tree combines the lanes.  `raw` must not alias the partial buffer (fp32 partials, fp64 result).
+// from_state (the scan ran with SNN_SCAN_SUMS_FROM_STATE): the second partial is sum(gx * x); raw still receives sum(gx * y)
+// = mean * sum(gx) + (sum(gx * x) - bias * sum(gx)) / (gamma * invstd) - what the all-reduce and k_bn_bwd_coef expect - and
+// the sum itself, from gx and y, for a channel whose gamma is exactly 0 (see k_bn_bwd_finalize_fused).
+__device__ __forceinline__ double sum_gx_y_from_state(double s1, double p, double mu, double is, double gam, double bnb) {
+    return mu * s1 + (p - bnb * s1) / (gam * is);
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict__ sums_, int gx_blocks, int T, int C,
-                                                       double* __restrict__ raw) {
+                                                       double* __restrict__ raw, int from_state, int64_t M,
+                                                       const float* __restrict__ gamma, const float* __restrict__ bn_bias,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gx, const float* __restrict__ y,
+                                                       int64_t ldy) {
     const float* __restrict__ sums = reinterpret_cast<const float*>(sums_);
     const int sub = threadIdx.x & 31;
     const int idx = blockIdx.x * (blockDim.x / 32) + (threadIdx.x >> 5);
     const bool live = idx < T * C;
+    const int c = live ? idx % C : 0, t = live ? idx / C : 0;
+    const double gam = (double)((from_state && gamma) ? gamma[c] : 1.0f);
+    const bool direct = from_state && gam == 0.0;   // uniform over the 32 lanes of an (t, c)
     double s1 = 0.0, sy = 0.0;
     if (live) {
         for (int b = sub; b < gx_blocks; b += 32) {
@@ -1187,12 +1264,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const double* __restrict_
             s1 += (double)v.x;
             sy += (double)v.y;
         }
+        if (direct) {
+            sy = 0.0;
+            for (int64_t m = sub; m < M; m += 32)
+                sy += (double)gx[((int64_t)t * M + m) * C + c] * (double)y[((int64_t)t * M + m) * ldy + c];
+        }
     }
     for (int stride = 16; stride >= 1; stride >>= 1) {
         s1 += __shfl_xor(s1, stride, 64);
         sy += __shfl_xor(sy, stride, 64);
     }
     if (!live || sub != 0) return;
+    if (from_state && !direct)
+        sy = sum_gx_y_from_state(s1, sy, (double)mean[idx], (double)invstd[idx], gam, (double)(bn_bias ? bn_bias[c] : 0.0f));
     raw[(int64_t)idx * 2 + 0] = s1;
     raw[(int64_t)idx * 2 + 1] = sy;
 }
@@ -1240,13 +1324,19 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize_fused(
     const double* __restrict__ sums_, int gx_blocks, int T, int64_t M, int C, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coefA,
     float* __restrict__ coefB, float* __restrict__ coefC, float* __restrict__ dgamma, float* __restrict__ dbias,
-    int accumulate) {
+    int accumulate, int from_state, const float* __restrict__ bn_bias, const float* __restrict__ gx,
+    const float* __restrict__ y, int64_t ldy) {
+    // from_state (the scan ran with SNN_SCAN_SUMS_FROM_STATE): the second partial is sum(gx * x), x = gamma*xhat + bias the
+    // neuron's input, so sum(gx * xhat) = (sum(gx * x) - bias * sum(gx)) / gamma.  A channel whose gamma is exactly 0 carries
+    // no xhat in x: for it (and only for it) the sum is formed here from gx and y - slow, one block per such channel.
     const float* __restrict__ sums = reinterpret_cast<const float*>(sums_);  // fp32 block partials
     __shared__ double sm_b[32], sm_g[32];
     const int c = blockIdx.x;
     const int sub = threadIdx.x & 31, tl = threadIdx.x >> 5;
     double dg = 0.0, db = 0.0;
     const double gam = (double)(gamma ? gamma[c] : 1.0f);
+    const double bnb = (double)((from_state && bn_bias) ? bn_bias[c] : 0.0f);
+    const bool direct = from_state && gam == 0.0;
     for (int tb = 0; tb < T; tb += 32) {
         const int t = tb + tl;
         const int idx = t * C + c;
@@ -1259,12 +1349,20 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize_fused(
                 sy += (double)v.y;
             }
         }
+        if (direct) {   // uniform over the block
+            sy = 0.0;
+            if (t < T) {
+                for (int64_t m = sub; m < M; m += 32)
+                    sy += (double)gx[((int64_t)t * M + m) * C + c] * (double)y[((int64_t)t * M + m) * ldy + c];
+            }
+        }
         for (int stride = 16; stride >= 1; stride >>= 1) {
             s1 += __shfl_xor(s1, stride, 64);
             sy += __shfl_xor(sy, stride, 64);
         }
         if (sub == 0 && t < T) {
             const double mu = (double)mean[idx], is = (double)invstd[idx];
+            if (from_state && !direct) sy = sum_gx_y_from_state(s1, sy, mu, is, gam, bnb);   // (as k_bn_bwd_reduce: same bits)
             const double s2 = is * (sy - mu * s1);  // sum gx * xhat
             const double n = (double)M;
             const double a = gam * is;
@@ -1574,14 +1672,53 @@ extern "C" size_t snn_affine_neuron_bwd_sums_size(int T, int64_t M, int C) {
         }                                                         \
     } while (0)
 
+static bool sums_from_state_ok(int neuron, int T, int64_t M, int C, int64_t ldg, const snn_neuron_params* p, int flags) {
+    if (neuron != SNN_NEURON_LIF || !p || T <= 0 || M <= 0 || C <= 0 || ldg < C) return false;
+    if (flags & (SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE)) return false;
+    // the rebuilt input divides by c_mem: keep the amplification of the potentials' rounding error bounded
+    if (!(p->c_mem >= 1.0f / 64.0f && p->c_mem <= 1.0f)) return false;
+    const BwdPlan pl = bwd_plan(T, M, C, true);
+    const int64_t ld_max = ldg > C ? ldg : C;
+    return pl.vec == 4 && pl.mode == 1 && ldg % 4 == 0 && M * ld_max * 4 < 0x7fffffffLL;
+}
+
+extern "C" int snn_affine_neuron_bwd_sums_from_state(int neuron, int T, int64_t M, int C, int64_t ldg,
+                                                     const snn_neuron_params* p, int flags) {
+    return sums_from_state_ok(neuron, T, M, C, ldg, p, flags) ? 1 : 0;
+}
+
 extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg, const float* state, const float* y,
                                      int64_t ldy, const float* g_vT, const float* g_iT, const float* alpha,
                                      const float* beta, int apply_scale, float* gx, float* g_v0, float* g_i0,
                                      double* sums, int T, int64_t M, int C, const snn_neuron_params* p,
                                      int flags, void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
-    SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE)) == 0,
+    SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE |
+                           SNN_SCAN_SUMS_FROM_STATE)) == 0,
                 "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
+    const bool yfree = (flags & SNN_SCAN_SUMS_FROM_STATE) != 0;
+    flags &= ~SNN_SCAN_SUMS_FROM_STATE;
+    if (yfree) {
+        SNN_REQUIRE(sums && state && !g_v0 && !g_i0 && !apply_scale && sums_from_state_ok(neuron, T, M, C, ldg, p, flags),
+                    "snn_affine_neuron_bwd: SNN_SCAN_SUMS_FROM_STATE not covered (ask snn_affine_neuron_bwd_sums_from_state; "
+                    "LIF from the initial state, sums wanted, train-mode BatchNorm)");
+        SNN_REQUIRE(aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) && aligned16(gx),
+                    "snn_affine_neuron_bwd: buffers must be 16-byte aligned");
+        const BwdPlan pl = bwd_plan(T, M, C, true);
+        dim3 grid(pl.gx, pl.gy);
+        // three pixels per thread: the four values a pixel keeps for the statistic of two steps later do not fit the
+        // 256 registers of two waves per SIMD beside four pixels' operand sets (287, or 21 spilled)
+#define SNN_LAUNCH_YF(NP_)                                                                                              \
+    hipLaunchKernelGGL((k_affine_neuron_bwd<SNN_NEURON_LIF, 4, 1, true, NP_, false, true>), grid, dim3(kThreads),         \
+                       pl.lds_bytes, (hipStream_t)stream, g_out, ldg, state, g_out, ldg, g_vT, g_iT, alpha, beta, 0, gx, \
+                       nullptr, nullptr, sums, T, M, C, pl.cvb, *p, 0)
+        if (pl.rpb == 1) SNN_LAUNCH_YF(1);
+        else if (pl.rpb == 2) SNN_LAUNCH_YF(2);
+        else SNN_LAUNCH_YF(3);
+#undef SNN_LAUNCH_YF
+        SNN_CHECK_LAUNCH("snn_affine_neuron_bwd");
+        return 0;
+    }
     const int last_only = (flags & SNN_SCAN_LAST_STEP_ONLY) != 0;
     const bool sb = (flags & SNN_SCAN_BF16_STORAGE) != 0;   // g_out, state, y, gx are bf16 tensors
     SNN_REQUIRE(!last_only || neuron == SNN_NEURON_LIF || neuron == SNN_NEURON_LI || neuron == SNN_NEURON_LI_TANH,
@@ -1702,8 +1839,24 @@ extern "C" int snn_bn_bwd_reduce(const double* sums, int T, int64_t M, int C, do
     SNN_REQUIRE(sums != raw, "snn_bn_bwd_reduce: raw must not alias the partial sums");
     BwdPlan pl = bwd_plan(T, M, C, true);
     int n = T * C;
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, C, raw);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, C, raw, 0, M,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     SNN_CHECK_LAUNCH("snn_bn_bwd_reduce");
+    return 0;
+}
+
+// the same for sums of a scan that ran with SNN_SCAN_SUMS_FROM_STATE: raw receives (sum gx, sum gx*y) all the same
+extern "C" int snn_bn_bwd_reduce_from_state(const double* sums, int T, int64_t M, int C, const float* gamma, const float* bias,
+                                            const float* mean, const float* invstd, const float* gx, const float* y,
+                                            int64_t ldy, double* raw, void* stream) {
+    SNN_REQUIRE(sums && raw && mean && invstd && gx && y && T > 0 && M > 0 && C > 0 && ldy >= C,
+                "snn_bn_bwd_reduce_from_state: bad arguments");
+    SNN_REQUIRE(sums != raw, "snn_bn_bwd_reduce_from_state: raw must not alias the partial sums");
+    BwdPlan pl = bwd_plan(T, M, C, true);
+    int n = T * C;
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, sums, pl.gx, T, C, raw, 1, M,
+                       gamma, bias, mean, invstd, gx, y, ldy);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_reduce_from_state");
     return 0;
 }
 
@@ -1734,8 +1887,22 @@ extern "C" int snn_bn_bwd_finalize(double* sums, int T, int64_t M, int C, const 
     SNN_REQUIRE(T > 0 && M > 0 && C > 0, "snn_bn_bwd_finalize: bad shape");
     BwdPlan pl = bwd_plan(T, M, C, true);
     hipLaunchKernelGGL(k_bn_bwd_finalize_fused, dim3(C), dim3(1024), 0, (hipStream_t)stream, sums, pl.gx, T, M, C, gamma,
-                       mean, invstd, coefA, coefB, coefC, dgamma, dbias, accumulate);
+                       mean, invstd, coefA, coefB, coefC, dgamma, dbias, accumulate, 0, nullptr, nullptr, nullptr, 0);
     SNN_CHECK_LAUNCH("snn_bn_bwd_finalize");
+    return 0;
+}
+
+// the same for sums written by a scan that ran with SNN_SCAN_SUMS_FROM_STATE (second partial: sum(gx * x), see the kernel)
+extern "C" int snn_bn_bwd_finalize_from_state(double* sums, int T, int64_t M, int C, const float* gamma, const float* bias,
+                                              const float* mean, const float* invstd, const float* gx, const float* y,
+                                              int64_t ldy, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                              float* dbias, int accumulate, void* stream) {
+    SNN_REQUIRE(sums && mean && invstd && coefA && coefB && coefC && gx && y, "snn_bn_bwd_finalize_from_state: null pointer");
+    SNN_REQUIRE(T > 0 && M > 0 && C > 0 && ldy >= C, "snn_bn_bwd_finalize_from_state: bad shape");
+    BwdPlan pl = bwd_plan(T, M, C, true);
+    hipLaunchKernelGGL(k_bn_bwd_finalize_fused, dim3(C), dim3(1024), 0, (hipStream_t)stream, sums, pl.gx, T, M, C, gamma,
+                       mean, invstd, coefA, coefB, coefC, dgamma, dbias, accumulate, 1, bias, gx, y, ldy);
+    SNN_CHECK_LAUNCH("snn_bn_bwd_finalize_from_state");
     return 0;
 }
 

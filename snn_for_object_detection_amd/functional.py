@@ -1267,6 +1267,10 @@ USE_PRESPLIT_WEIGHTS = not os.environ.get("SNN_NO_PRESPLIT_WEIGHTS")
 # scale, two conversions and a subtraction), so off by default: one launch and one weight-sized buffer less per step
 USE_PRESPLIT_DGRAD = bool(os.environ.get("SNN_PRESPLIT_DGRAD"))
 SCAN_FLAGS = 0   # flags of snn_affine_neuron_bwd; tests set _hip.SCAN_WIDE_ADDRESSING to cover the 64-bit-pointer scan
+# the reverse LIF scan of a train-mode Norm -> LIF layer does not read the convolution output y: the BatchNorm statistic it
+# needs y for is formed from the neuron input rebuilt from the saved potentials (snn_affine_neuron_bwd
+# SNN_SCAN_SUMS_FROM_STATE; SNN_NO_SUMS_FROM_STATE: tuning / bisecting aid)
+USE_SUMS_FROM_STATE = not os.environ.get("SNN_NO_SUMS_FROM_STATE")
 
 # Opt-in memory lever: a LIF layer whose per-step saved state ([T,B,H,W,C] fp32) is at least this many bytes stores
 # checkpoints of (v, i) every snn_lif_ckpt_interval() steps instead and recomputes in the backward scan
@@ -1418,7 +1422,7 @@ class _AffineNeuron(Function):
         if neuron == _hip.NEURON_LI_TANH and need_grad and not is_channels_last(out):
             raise RuntimeError("LI+Tanh output placed in a concat slice is not supported for training")
         state = vdec if neuron in _SAVES_STEP else (out if neuron == _hip.NEURON_LI_TANH else None)
-        ctx.save_for_backward(y, gamma, mean, invstd, alpha, beta, state)
+        ctx.save_for_backward(y, gamma, mean, invstd, alpha, beta, state, bias if has_bn else None)
         if not has_state:
             ctx.mark_non_differentiable(vT, iT)
         # with a neuron, vT / iT stay differentiable (time-outer BPTT through the carried state)
@@ -1428,7 +1432,7 @@ class _AffineNeuron(Function):
 
     @staticmethod
     def backward(ctx, g_out, g_vT, g_iT):
-        y, gamma, mean, invstd, alpha, beta, state = ctx.saved_tensors
+        y, gamma, mean, invstd, alpha, beta, state, bn_bias = ctx.saved_tensors
         neuron, has_bn, use_running, params, (T, B, C, H, W) = ctx.cfg
         M = B * H * W
         st = _stream()
@@ -1526,6 +1530,17 @@ class _AffineNeuron(Function):
                           invstd.data_ptr() + tc, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
                           coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)
                 gv_in, gi_in, first = gv_out, gi_out, False
+        sums_from_state = (USE_SUMS_FROM_STATE and need_sums and not segmented and not ctx.ckpt and not apply_scale
+                           and neuron == _hip.NEURON_LIF and not ctx.has_v0 and not ctx.has_i0
+                           and g_v0 is None and g_i0 is None
+                           and _hip.query("snn_affine_neuron_bwd_sums_from_state", neuron, T, M, C, ldg, params, scan_flags))
+        if segmented:
+            pass
+        elif sums_from_state:
+            # y is not read: the statistic comes from the neuron input rebuilt from the saved potentials
+            _hip.call("snn_affine_neuron_bwd", neuron, g_out.data_ptr(), ldg, _ptr(state), None, ldy,
+                      _ptr(g_vT), _ptr(g_iT), _ptr(alpha), _ptr(beta), 0, gx.data_ptr(), None, None, _ptr(sums), T, M, C,
+                      params, scan_flags | _hip.SCAN_SUMS_FROM_STATE, st)
         elif ctx.ckpt:
             _hip.call("snn_lif_bwd_ckpt", g_out.data_ptr(), ldg, state.data_ptr(), y.data_ptr(), ldy, _ptr(g_vT),
                       _ptr(g_iT), _ptr(alpha), _ptr(beta), apply_scale, gx.data_ptr(), _ptr(g_v0), _ptr(g_i0),
@@ -1537,7 +1552,11 @@ class _AffineNeuron(Function):
         if need_sums:
             if segmented:
                 pass   # coefficients and parameter gradients were finalised per segment
-            elif ctx.sync_group is None:
+            elif sums_from_state and ctx.sync_group is None:
+                _hip.call("snn_bn_bwd_finalize_from_state", sums.data_ptr(), T, M, C, _ptr(gamma), _ptr(bn_bias),
+                          mean.data_ptr(), invstd.data_ptr(), gx.data_ptr(), y.data_ptr(), ldy, coef[0].data_ptr(),
+                          coef[1].data_ptr(), coef[2].data_ptr(), dg_ptr, db_ptr, acc_flag, st)
+            elif ctx.sync_group is None and not sums_from_state:
                 _hip.call("snn_bn_bwd_finalize", sums.data_ptr(), T, M, C, _ptr(gamma), mean.data_ptr(),
                           invstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), dg_ptr,
                           db_ptr, acc_flag, st)
@@ -1547,7 +1566,11 @@ class _AffineNeuron(Function):
                 import torch.distributed as dist
                 world = dist.get_world_size(ctx.sync_group[0])
                 raw_local = torch.empty((T, C, 2), device=dev, dtype=torch.float64)
-                _hip.call("snn_bn_bwd_reduce", sums.data_ptr(), T, M, C, raw_local.data_ptr(), st)
+                if sums_from_state:
+                    _hip.call("snn_bn_bwd_reduce_from_state", sums.data_ptr(), T, M, C, _ptr(gamma), _ptr(bn_bias),
+                              mean.data_ptr(), invstd.data_ptr(), gx.data_ptr(), y.data_ptr(), ldy, raw_local.data_ptr(), st)
+                else:
+                    _hip.call("snn_bn_bwd_reduce", sums.data_ptr(), T, M, C, raw_local.data_ptr(), st)
                 raw = raw_local.clone()
                 dist.all_reduce(raw, op=dist.ReduceOp.SUM, group=ctx.sync_group[0])
                 param_sums = torch.empty((T, C, 2), device=dev, dtype=torch.float64)

@@ -125,7 +125,8 @@ def work_of(name: str, a):
         elems = float(T) * M * C
         one = 1.0 / T if last_only else 1
         saved = 0 if a[3] is None else (one if neuron == 3 else 1)   # LIF & co. save v_dec per step, LI+Tanh its output
-        tensors = one + 1 + saved + (1 if a[14] is not None else 0)   # g_out, gx, saved state, y (for the BN sums)
+        from_state = bool(a[19] & 16)   # SNN_SCAN_SUMS_FROM_STATE: the statistic comes from the saved state, y is not read
+        tensors = one + 1 + saved + (1 if (a[14] is not None and not from_state) else 0)   # g_out, gx, saved state, y (BN sums)
         sb = bool(a[19] & SCAN_BF16_STORAGE)
         return f"k_affine_neuron_bwd<{neuron}>" + (", bf16s" if sb else ""), 16.0 * elems, (2.0 if sb else 4.0) * elems * tensors
     if name == "snn_lif_fwd_ckpt":  # y, out (+ shortcut), checkpoints = 2/K of a tensor

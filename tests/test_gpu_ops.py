@@ -461,6 +461,8 @@ def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
     x = torch.randn(T, B, C, H, W).cuda().requires_grad_()
     g = torch.randn(T, B, C, H, W).cuda()
     results = []
+    was = HF.USE_SUMS_FROM_STATE
+    HF.USE_SUMS_FROM_STATE = False   # both forms of the scan that READS y (the other one has a buffer-addressed form only)
     for no_buf in (False, True):
         HF.SCAN_FLAGS = _hip.SCAN_WIDE_ADDRESSING if no_buf else 0
         try:
@@ -469,6 +471,7 @@ def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
             results.append(torch.autograd.grad(out, (y, x, bn.weight, bn.bias), g))
         finally:
             HF.SCAN_FLAGS = 0
+    HF.USE_SUMS_FROM_STATE = was
     ordered = (C // 4) & (C // 4 - 1) == 0
     for a, b in zip(*results):
         assert torch.isfinite(a).all()
@@ -476,6 +479,63 @@ def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
             assert torch.equal(a, b)
         else:
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,H,W,T,B,shortcut", [(64, 60, 76, 8, 5, True), (32, 120, 152, 3, 2, False), (128, 15, 19, 5, 2, True),
+                                                   (256, 8, 10, 4, 5, False), (64, 9, 11, 1, 2, False), (32, 6, 7, 2, 3, True),
+                                                   (128, 30, 38, 32, 2, True)])
+def test_reverse_scan_statistic_from_the_saved_state(HF, C, H, W, T, B, shortcut):
+    """SNN_SCAN_SUMS_FROM_STATE: the reverse LIF scan of a train-mode Norm -> LIF layer does not read y; the BatchNorm
+    statistic sum(gx * y) is replaced by sum(gx * x) with the neuron input x rebuilt from the saved potentials
+    (snn_bn_bwd_finalize_from_state converts).  Against the scan that reads y: the recurrence is untouched, so everything
+    that does not pass through the statistic is bit-identical (shortcut gradient, dbias = sum gx); dy / dgamma agree to the
+    rounding of the rebuilt input (1e-6 relative measured; asserted 1e-5).  One channel has gamma == 0 exactly - x then holds
+    no trace of y and the finalize kernel sums gx * y for that channel itself - and the bias is not zero.
+    Cases: three / two / one pixel rows per thread, T = 1 and 2 (the two statistics owed after the loop), T = 32."""
+    from snn_for_object_detection_amd import _hip
+    torch.manual_seed(C + H + T)
+    y = (2.5 * torch.randn(T, B, C, H, W) + 0.3).cuda().requires_grad_()
+    x = torch.randn(T, B, C, H, W).cuda().requires_grad_() if shortcut else None
+    g = torch.randn(T, B, C, H, W).cuda()
+    gamma = 1.0 + 0.3 * torch.randn(C)
+    gamma[1] = 0.0
+    gamma[2] = -0.7
+    bias = 0.4 * torch.randn(C)
+    results, flags = [], []
+    for on in (True, False):
+        was = HF.USE_SUMS_FROM_STATE
+        HF.USE_SUMS_FROM_STATE = on
+        calls = []
+
+        class Spy:
+            def before(self, name, args):
+                calls.append((name, args))
+
+            def after(self, tok):
+                pass
+        _hip.PROFILER = Spy()
+        try:
+            bn = torch.nn.BatchNorm2d(C).cuda().train()
+            bn.weight.data.copy_(gamma)
+            bn.bias.data.copy_(bias)
+            out, st = HF.affine_neuron(y, _hip.NEURON_LIF, None, bn=bn, addend=x)
+            inputs = (y, bn.weight, bn.bias) + ((x,) if shortcut else ())
+            results.append(torch.autograd.grad(out, inputs, g))
+        finally:
+            _hip.PROFILER = None
+            HF.USE_SUMS_FROM_STATE = was
+        flags.append([a[19] for nm, a in calls if nm == "snn_affine_neuron_bwd"])
+        names = [nm for nm, _ in calls]
+        assert ("snn_bn_bwd_finalize_from_state" in names) == on and ("snn_bn_bwd_finalize" in names) == (not on)
+    assert flags[0] == [_hip.SCAN_SUMS_FROM_STATE] and flags[1] == [0]
+    (dy1, dg1, db1, *rest1), (dy0, dg0, db0, *rest0) = results
+    assert torch.isfinite(dy1).all() and float(dy0.abs().sum()) > 0
+    assert torch.equal(db1, db0)
+    if shortcut:
+        assert torch.equal(rest1[0], rest0[0])
+    assert rel_err(dy1, dy0) < 1e-5 and rel_err(dg1, dg0) < 1e-5
+    assert abs(float(dg1[1] - dg0[1])) <= 1e-5 * max(1.0, abs(float(dg0[1])))     # the gamma == 0 channel: summed directly
+    assert float(dy1[:, :, 1].abs().max()) == 0.0 and float(dy0[:, :, 1].abs().max()) == 0.0
 
 
 def _oracle_norm_neuron(y, bn, cell, tanh=False, state=None):
