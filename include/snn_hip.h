@@ -90,13 +90,18 @@ enum { SNN_SCAN_WIDE_ADDRESSING = 1, /* bwd: use 64-bit pointer addressing even 
                                         the spikes, z = (v_dec > v_th), and the consumer forms them while it reads them
                                         (snn_conv1x1_spikes_fwd / _wgrad): 4 of the 12 bytes the scan moves per
                                         neuron-timestep never exist.  fp32 tensors, C and ldy multiples of 4 */
-       SNN_SCAN_SUMS_FROM_STATE = 16 /* bwd, LIF from the initial state with `sums` wanted: y is NOT read (NULL allowed).
+       SNN_SCAN_SUMS_FROM_STATE = 16,/* bwd, LIF from the initial state with `sums` wanted: y is NOT read (NULL allowed).
                                         The BatchNorm statistic the scan needs y for, sum(gx * y), is replaced by
                                         sum(gx * x) with the neuron's input x[t] = alpha*y[t] + beta rebuilt from the saved
                                         potentials (vd[t], vd[t-1], vd[t-2] and the reset rule determine x[t] to fp32
                                         rounding): 4 of the 16 bytes per neuron-timestep are never read.  The sums must
                                         then go through snn_bn_bwd_finalize_from_state.  Covered cases:
-                                        snn_affine_neuron_bwd_sums_from_state(); g_v0 / g_i0 must be NULL */ };
+                                        snn_affine_neuron_bwd_sums_from_state().  The sequence must start from the
+                                        initial state (v_leak, 0) - or carry the next flag */
+       SNN_SCAN_STATE_LOOKBACK = 32  /* with SNN_SCAN_SUMS_FROM_STATE, for a SEGMENT [t0, t0 + T) of a longer saved
+                                        sequence, t0 >= 2: `state` points at step t0 and state[-1], state[-2] (the two
+                                        steps in front of it, same [M][C] layout) are read to rebuild the neuron state
+                                        the segment starts from */ };
 
 /* pooling kinds, layer_gen.py:139-173 / common.py:18-49 */
 enum { SNN_POOL_AVG = 0, SNN_POOL_MAX = 1, SNN_POOL_SUM = 2 };

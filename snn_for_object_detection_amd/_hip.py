@@ -18,6 +18,7 @@ ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
 ABI_VERSION = 10
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE, SCAN_SPIKES_FROM_VDEC, SCAN_SUMS_FROM_STATE = 1, 2, 4, 8, 16
+SCAN_STATE_LOOKBACK = 32
 
 
 class NeuronParams(Structure):

@@ -643,9 +643,12 @@ __global__ __launch_bounds__(kThreads, YF ? 2 : 1) void k_affine_neuron_bwd(
     int64_t ldy, const float* __restrict__ g_vT, const float* __restrict__ g_iT, const float* __restrict__ alpha,
     const float* __restrict__ beta, int apply_scale, float* __restrict__ gx, float* __restrict__ g_v0,
     float* __restrict__ g_i0, double* __restrict__ sums, int T, int64_t M, int C, int cvb, snn_neuron_params p,
-    int last_only) {
+    int last_only_or_lookback) {
     // last_only (SNN_SCAN_LAST_STEP_ONLY; LIF / LI / LI+Tanh): g_out (and LI+Tanh's saved output) are [M][..] tensors of
-    // the LAST timestep; the output gradient of every earlier step is zero and nothing is read for it
+    // the LAST timestep; the output gradient of every earlier step is zero and nothing is read for it.
+    // YF instances (never last_only) take SNN_SCAN_STATE_LOOKBACK in the same argument slot.
+    const int last_only = YF ? 0 : last_only_or_lookback;
+    [[maybe_unused]] const int lookback = YF ? last_only_or_lookback : 0;
     typedef typename Vec<VEC>::type V;
     constexpr int ES = SnnStore<SB>::ES;   // bytes per element of the activation tensors
     constexpr bool kNeedsX = (NEURON == SNN_NEURON_SLI || NEURON == SNN_NEURON_SYNAPSE);
@@ -966,8 +969,19 @@ __global__ __launch_bounds__(kThreads, YF ? 2 : 1) void k_affine_neuron_bwd(
             }
         }
         if constexpr (YF) {
-            // the two statistics the loop still owes: x[1] = i'[1] - i[0] and x[0] = i'[0] - 0, i'[0] from the initial
-            // state v = v_leak (after the loop: vd1 = vd[0], in2 = i'[1], g1 = gx[0], g2 = gx[1])
+            // the two statistics the loop still owes: x[1] = i'[1] - i[0] and x[0] = i'[0] - i[-1] (after the loop: vd1 =
+            // vd[0], in2 = i'[1], g1 = gx[0], g2 = gx[1]).  The state before step 0 is the initial one, (v_leak, 0) - or,
+            // for a segment of a longer scan (SNN_SCAN_STATE_LOOKBACK), what the two saved potentials in front of the
+            // segment say: v[-1] from vd[-1], i[-1] from vd[-1] and vd[-2].
+            V vm1[NP], vm2[NP];
+            if (lookback) {
+                const __amdgpu_buffer_rsrc_t rs1 = slab(state, -1, C), rs2 = slab(state, -2, C);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    vm1[q] = bload(rs1, os[q]);
+                    vm2[q] = bload(rs2, os[q]);
+                }
+            }
             float sa[VEC], sb0[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sa[j] = sb0[j] = 0.0f;
@@ -975,10 +989,18 @@ __global__ __launch_bounds__(kThreads, YF ? 2 : 1) void k_affine_neuron_bwd(
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float in0 = (lane<VEC>(yf_vd1[q], j) - p.v_leak) * inv_cmem;   // - (v_leak - v_leak)
+                    float vp1 = p.v_leak, ip = 0.0f;
+                    if (lookback) {
+                        const float a = lane<VEC>(vm1[q], j), b = lane<VEC>(vm2[q], j);
+                        const float vp2 = (b - p.v_th > 0.0f) ? p.v_reset : b;
+                        const float im1 = (a - vp2) * inv_cmem - (p.v_leak - vp2);
+                        ip = im1 + p.c_syn * im1;
+                        vp1 = (a - p.v_th > 0.0f) ? p.v_reset : a;
+                    }
+                    const float in0 = (lane<VEC>(yf_vd1[q], j) - vp1) * inv_cmem - (p.v_leak - vp1);
                     const float x1 = lane<VEC>(yf_in2[q], j) - (in0 + p.c_syn * in0);
                     sa[j] += lane<VEC>(yf_g2[q], j) * x1;
-                    sb0[j] += lane<VEC>(yf_g1[q], j) * in0;
+                    sb0[j] += lane<VEC>(yf_g1[q], j) * (in0 - ip);
                 }
             }
             wave_sum_channels<VEC>(sa, sb0, cvb);
@@ -1694,16 +1716,18 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
                                      int flags, void* stream) {
     SNN_REQUIRE(g_out && gx && p, "snn_affine_neuron_bwd: null pointer");
     SNN_REQUIRE((flags & ~(SNN_SCAN_WIDE_ADDRESSING | SNN_SCAN_LAST_STEP_ONLY | SNN_SCAN_BF16_STORAGE |
-                           SNN_SCAN_SUMS_FROM_STATE)) == 0,
+                           SNN_SCAN_SUMS_FROM_STATE | SNN_SCAN_STATE_LOOKBACK)) == 0,
                 "snn_affine_neuron_bwd: unknown flags 0x%x", flags);
     const bool yfree = (flags & SNN_SCAN_SUMS_FROM_STATE) != 0;
-    flags &= ~SNN_SCAN_SUMS_FROM_STATE;
+    const int lookback = (flags & SNN_SCAN_STATE_LOOKBACK) != 0;
+    SNN_REQUIRE(yfree || !lookback, "snn_affine_neuron_bwd: SNN_SCAN_STATE_LOOKBACK belongs to SNN_SCAN_SUMS_FROM_STATE");
+    flags &= ~(SNN_SCAN_SUMS_FROM_STATE | SNN_SCAN_STATE_LOOKBACK);
     if (yfree) {
-        SNN_REQUIRE(sums && state && !g_v0 && !g_i0 && !apply_scale && sums_from_state_ok(neuron, T, M, C, ldg, p, flags),
+        SNN_REQUIRE(sums && state && !apply_scale && sums_from_state_ok(neuron, T, M, C, ldg, p, flags),
                     "snn_affine_neuron_bwd: SNN_SCAN_SUMS_FROM_STATE not covered (ask snn_affine_neuron_bwd_sums_from_state; "
                     "LIF from the initial state, sums wanted, train-mode BatchNorm)");
-        SNN_REQUIRE(aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) && aligned16(gx),
-                    "snn_affine_neuron_bwd: buffers must be 16-byte aligned");
+        SNN_REQUIRE(aligned16(g_out) && aligned16(state) && aligned16(g_vT) && aligned16(g_iT) && aligned16(gx) &&
+                    aligned16(g_v0) && aligned16(g_i0), "snn_affine_neuron_bwd: buffers must be 16-byte aligned");
         const BwdPlan pl = bwd_plan(T, M, C, true);
         dim3 grid(pl.gx, pl.gy);
         // three pixels per thread: the four values a pixel keeps for the statistic of two steps later do not fit the
@@ -1711,7 +1735,7 @@ extern "C" int snn_affine_neuron_bwd(int neuron, const float* g_out, int64_t ldg
 #define SNN_LAUNCH_YF(NP_)                                                                                              \
     hipLaunchKernelGGL((k_affine_neuron_bwd<SNN_NEURON_LIF, 4, 1, true, NP_, false, true>), grid, dim3(kThreads),         \
                        pl.lds_bytes, (hipStream_t)stream, g_out, ldg, state, g_out, ldg, g_vT, g_iT, alpha, beta, 0, gx, \
-                       nullptr, nullptr, sums, T, M, C, pl.cvb, *p, 0)
+                       g_v0, g_i0, sums, T, M, C, pl.cvb, *p, lookback)
         if (pl.rpb == 1) SNN_LAUNCH_YF(1);
         else if (pl.rpb == 2) SNN_LAUNCH_YF(2);
         else SNN_LAUNCH_YF(3);

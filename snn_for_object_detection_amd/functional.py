@@ -1498,6 +1498,14 @@ class _AffineNeuron(Function):
         # segment boundary through (g_v, g_i), which the kernel already takes and returns: same values bit for bit.
         segmented = (need_sums and has_state and not ctx.ckpt and ctx.sync_group is None and SCAN_SEGMENT_T
                      and T > SCAN_SEGMENT_T)
+        # (segments: every segment must be covered; a segment behind the first one finds the neuron state it starts from
+        # in the two saved potentials in front of it - SNN_SCAN_STATE_LOOKBACK)
+        sums_from_state = bool(
+            USE_SUMS_FROM_STATE and need_sums and not ctx.ckpt and not apply_scale and neuron == _hip.NEURON_LIF
+            and not ctx.has_v0 and not ctx.has_i0 and g_v0 is None and g_i0 is None
+            and not (segmented and T % SCAN_SEGMENT_T == 1)    # (a second segment starting at step 1 has one step to look back on)
+            and all(_hip.query("snn_affine_neuron_bwd_sums_from_state", neuron, ts_, M, C, ldg, params, scan_flags)
+                    for ts_ in ({SCAN_SEGMENT_T, T % SCAN_SEGMENT_T or SCAN_SEGMENT_T} if segmented else {T})))
         if segmented:
             fr_g, fr_y, fr_c = M * ldg * es, M * ldy * es, M * C * es    # bytes per timestep of g_out / y / dense tensors
             gv_in, gi_in = g_vT, g_iT
@@ -1521,19 +1529,24 @@ class _AffineNeuron(Function):
                         g_none = torch.zeros_like(g_out)
                     g_seg = g_none.data_ptr()
                 st_off = 0 if (ctx.last_only and neuron == _hip.NEURON_LI_TANH) else t0 * fr_c   # saved output: last step only
+                seg_flags = scan_flags
+                if sums_from_state:
+                    seg_flags |= _hip.SCAN_SUMS_FROM_STATE | (_hip.SCAN_STATE_LOOKBACK if t0 > 0 else 0)
                 _hip.call("snn_affine_neuron_bwd", neuron, g_seg, ldg,
                           None if state is None else state.data_ptr() + st_off, y.data_ptr() + t0 * fr_y, ldy,
                           _ptr(gv_in), _ptr(gi_in), None if alpha is None else alpha.data_ptr() + tc,
                           None if beta is None else beta.data_ptr() + tc, apply_scale, gx.data_ptr() + t0 * fr_c,
-                          gv_out.data_ptr(), gi_out.data_ptr(), seg_sums.data_ptr(), ts, M, C, params, scan_flags, st)
-                _hip.call("snn_bn_bwd_finalize", seg_sums.data_ptr(), ts, M, C, _ptr(gamma), mean.data_ptr() + tc,
-                          invstd.data_ptr() + tc, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
-                          coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)
+                          gv_out.data_ptr(), gi_out.data_ptr(), seg_sums.data_ptr(), ts, M, C, params, seg_flags, st)
+                if sums_from_state:
+                    _hip.call("snn_bn_bwd_finalize_from_state", seg_sums.data_ptr(), ts, M, C, _ptr(gamma), _ptr(bn_bias),
+                              mean.data_ptr() + tc, invstd.data_ptr() + tc, gx.data_ptr() + t0 * fr_c,
+                              y.data_ptr() + t0 * fr_y, ldy, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
+                              coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)
+                else:
+                    _hip.call("snn_bn_bwd_finalize", seg_sums.data_ptr(), ts, M, C, _ptr(gamma), mean.data_ptr() + tc,
+                              invstd.data_ptr() + tc, coef[0].data_ptr() + tc, coef[1].data_ptr() + tc,
+                              coef[2].data_ptr() + tc, dg_ptr, db_ptr, acc_flag if first else 1, st)
                 gv_in, gi_in, first = gv_out, gi_out, False
-        sums_from_state = (USE_SUMS_FROM_STATE and need_sums and not segmented and not ctx.ckpt and not apply_scale
-                           and neuron == _hip.NEURON_LIF and not ctx.has_v0 and not ctx.has_i0
-                           and g_v0 is None and g_i0 is None
-                           and _hip.query("snn_affine_neuron_bwd_sums_from_state", neuron, T, M, C, ldg, params, scan_flags))
         if segmented:
             pass
         elif sums_from_state:

@@ -483,7 +483,7 @@ def test_backward_scan_addressing_variants_agree(HF, C, H, W, T, B):
 
 @pytest.mark.parametrize("C,H,W,T,B,shortcut", [(64, 60, 76, 8, 5, True), (32, 120, 152, 3, 2, False), (128, 15, 19, 5, 2, True),
                                                    (256, 8, 10, 4, 5, False), (64, 9, 11, 1, 2, False), (32, 6, 7, 2, 3, True),
-                                                   (128, 30, 38, 32, 2, True)])
+                                                   (128, 30, 38, 32, 2, True), (64, 12, 10, 70, 2, True)])
 def test_reverse_scan_statistic_from_the_saved_state(HF, C, H, W, T, B, shortcut):
     """SNN_SCAN_SUMS_FROM_STATE: the reverse LIF scan of a train-mode Norm -> LIF layer does not read y; the BatchNorm
     statistic sum(gx * y) is replaced by sum(gx * x) with the neuron input x rebuilt from the saved potentials
@@ -491,7 +491,9 @@ def test_reverse_scan_statistic_from_the_saved_state(HF, C, H, W, T, B, shortcut
     that does not pass through the statistic is bit-identical (shortcut gradient, dbias = sum gx); dy / dgamma agree to the
     rounding of the rebuilt input (1e-6 relative measured; asserted 1e-5).  One channel has gamma == 0 exactly - x then holds
     no trace of y and the finalize kernel sums gx * y for that channel itself - and the bias is not zero.
-    Cases: three / two / one pixel rows per thread, T = 1 and 2 (the two statistics owed after the loop), T = 32."""
+    Cases: three / two / one pixel rows per thread, T = 1 and 2 (the two statistics owed after the loop), T = 32, and T = 70
+    in three segments (SNN_SCAN_STATE_LOOKBACK: a segment behind the first one rebuilds the state it starts from out of the two
+    saved potentials in front of it)."""
     from snn_for_object_detection_amd import _hip
     torch.manual_seed(C + H + T)
     y = (2.5 * torch.randn(T, B, C, H, W) + 0.3).cuda().requires_grad_()
@@ -527,7 +529,11 @@ def test_reverse_scan_statistic_from_the_saved_state(HF, C, H, W, T, B, shortcut
         flags.append([a[19] for nm, a in calls if nm == "snn_affine_neuron_bwd"])
         names = [nm for nm, _ in calls]
         assert ("snn_bn_bwd_finalize_from_state" in names) == on and ("snn_bn_bwd_finalize" in names) == (not on)
-    assert flags[0] == [_hip.SCAN_SUMS_FROM_STATE] and flags[1] == [0]
+    if T <= 32:
+        assert flags[0] == [_hip.SCAN_SUMS_FROM_STATE] and flags[1] == [0]
+    else:   # last segment first; the one that starts at step 0 looks back on nothing
+        look = _hip.SCAN_SUMS_FROM_STATE | _hip.SCAN_STATE_LOOKBACK
+        assert flags[0] == [look, look, _hip.SCAN_SUMS_FROM_STATE] and flags[1] == [0, 0, 0]
     (dy1, dg1, db1, *rest1), (dy0, dg0, db0, *rest0) = results
     assert torch.isfinite(dy1).all() and float(dy0.abs().sum()) > 0
     assert torch.equal(db1, db0)
@@ -641,12 +647,17 @@ def test_last_step_only_lif_long_sequence_in_segments(HF):
     x = torch.randn(T, B, C, H, W, device="cuda") * 2
     g_last = torch.randn(B, C, H, W, device="cuda")
     res = []
-    for last_only in (True, False):
-        bn = HipBatchNorm2d(C).cuda().train()
-        xin = x.clone().requires_grad_()
-        out, st = HF.affine_neuron(xin, _hip.NEURON_LIF, None, bn=bn, last_only=last_only)
-        (out if last_only else out[-1]).backward(g_last)
-        res.append(((out if last_only else out[-1]).detach(), xin.grad, bn.weight.grad, st.v.detach(), st.i.detach()))
+    was = HF.USE_SUMS_FROM_STATE
+    HF.USE_SUMS_FROM_STATE = False   # the full scan that reads y, as the last-step-only one does: same bits
+    try:
+        for last_only in (True, False):
+            bn = HipBatchNorm2d(C).cuda().train()
+            xin = x.clone().requires_grad_()
+            out, st = HF.affine_neuron(xin, _hip.NEURON_LIF, None, bn=bn, last_only=last_only)
+            (out if last_only else out[-1]).backward(g_last)
+            res.append(((out if last_only else out[-1]).detach(), xin.grad, bn.weight.grad, st.v.detach(), st.i.detach()))
+    finally:
+        HF.USE_SUMS_FROM_STATE = was
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert res[0][0].sum() > 0 and res[0][1].abs().sum() > 0
