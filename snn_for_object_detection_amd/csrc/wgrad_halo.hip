@@ -379,8 +379,16 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
     // ---- waves: 32 output channels each; narrow layers split the K-steps of a patch over the waves instead
     p.wco = Cout >= 128 ? 4 : (Cout >= 64 ? 2 : 1);
     p.wk = 4 / p.wco;
-    // ---- patch shape: the useful share of the executed K-steps first (counting the idle waves of a K-split whose
-    // step count is not a multiple of wk), then the halo bytes per output pixel
+    // ---- patch shape: least time per image in a model of what a patch costs - its K-steps per wave (27 MFMAs of 32
+    // cycles each) plus a FIXED part, the staging of its halo between two barriers (load_halo / write_halo run their eight
+    // slots whatever the halo size) - then the halo bytes per output pixel.  Round 2 ranked by the useful share of the
+    // executed K-steps alone and gave the 32 -> 32 layer at 120x152 8x8 patches: no masked pixel, but ONE K-step per wave and
+    // patch - in-kernel stamps: 6 800 cycles per patch in staging (unchanged with every global load removed), as long as in
+    // the K loops.  With 12x16 patches (three K-steps per wave and patch) 327 -> 232-244 us.  The fixed part is what the
+    // co-resident block does NOT hide: 600 cycles reproduce both that gain and the measured tie between 10x8 and 4x40
+    // patches on the 128-channel layers at 30x38 (3 000, the stamp-based guess, predicted 15 % for 4x40: measured -3 %).
+    const char* cs_env = snn_tuning_env("SNN_HALO_PATCH_CYCLES");   // tuning builds: 0 = the round-2 ranking
+    const double stage_cycles = cs_env ? atof(cs_env) : 600.0;
     double best = -1.0;
     for (int cw = 8; cw <= 64; cw += 8) {   // multiples of 8: a K-step's group of 8 pixels never straddles two rows
         if (cw >= Wo + 8) break;
@@ -394,7 +402,9 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
             const int nks_w = (nks + p.wk - 1) / p.wk * p.wk;
             const double eff = (double)Ho * Wo / ((double)npr * npc * nks_w * 16);
             const double halo_per_px = (double)((r - 1) * stride + 3) * hc / ((double)r * cw * stride * stride);
-            const double score = eff - 0.03 * halo_per_px + 1e-4 * r * cw / 256.0;
+            double score = eff - 0.03 * halo_per_px + 1e-4 * r * cw / 256.0;
+            if (stage_cycles > 0.0)   // pixels per cycle of the model, the halo overhead as the tie-break
+                score = (double)Ho * Wo / ((double)npr * npc * ((nks_w / p.wk) * 864.0 + stage_cycles)) - 1e-4 * halo_per_px;
             if (score > best) {
                 best = score;
                 p.R = r; p.CW = cw; p.npr = npr; p.npc = npc; p.nks = nks;
