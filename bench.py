@@ -654,6 +654,14 @@ def main():
                                  "fp32": "exact fp32 MFMA"}[args.backward_precision],
                 "loss": float(loss.item()),
                 "peak_hbm_gib": peak_gib,
+                # what the opt-in bf16-STORAGE mode is held to (asserted on the GPU by tests/test_gpu_bf16_storage.py): not the
+                # 1e-4 parity contract of the fp32 line
+                **({"tolerances": {"convolution_rel_l2_vs_fp64_of_the_stored_operands": 3e-3,
+                                   "weight_gradient_rel_l2_vs_fp64_of_the_stored_operands": 2e-5,
+                                   "scans_and_batchnorm_apply": "the fp32 kernels' results rounded once to bf16 (bit-equal)",
+                                   "training_step_loss_rel_vs_fp32_oracle": 0.06,
+                                   "first_layer_weight_gradient_vs_fp32_oracle": "cosine > 0.6, rel. L2 < 1.0",
+                                   "asserted_by": "tests/test_gpu_bf16_storage.py"}} if sb else {}),
             },
             "dist": {"backend": backend, "world_size": world,
                      "gradient_exchange": ("SUM all-reduce of the flat fp32 gradient: neck + head part started from a backward "
