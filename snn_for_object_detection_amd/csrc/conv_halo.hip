@@ -93,6 +93,29 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
     }
 }
 
+// Wave combine of the fp64 statistics partials without LDS: value of lane l ^ 8 (DPP rotation inside a 16-lane row: every
+// lane), l ^ 16 (v_permlane16_swap: valid in the ODD 16-lane rows) and l ^ 32 (v_permlane32_swap: valid in the UPPER 32
+// lanes) - taken in this order the complete sum stands in lanes 48..63, through the same addition tree as an xor-shuffle
+// ladder (same bits), with VALU moves instead of two ds_bpermute round trips per value and stride.
+__device__ __forceinline__ double partner8(double v) {
+    const u32x2 u = __builtin_bit_cast(u32x2, v);
+    const u32x2 o = {(unsigned)__builtin_amdgcn_update_dpp(0, (int)u[0], 0x128, 0xf, 0xf, false),   // row_ror:8
+                     (unsigned)__builtin_amdgcn_update_dpp(0, (int)u[1], 0x128, 0xf, 0xf, false)};
+    return __builtin_bit_cast(double, o);
+}
+__device__ __forceinline__ double partner16(double v) {
+    const u32x2 u = __builtin_bit_cast(u32x2, v);
+    const u32x2 o = {__builtin_amdgcn_permlane16_swap(u[0], u[0], false, false)[0],
+                     __builtin_amdgcn_permlane16_swap(u[1], u[1], false, false)[0]};
+    return __builtin_bit_cast(double, o);
+}
+__device__ __forceinline__ double partner32(double v) {
+    const u32x2 u = __builtin_bit_cast(u32x2, v);
+    const u32x2 o = {__builtin_amdgcn_permlane32_swap(u[0], u[0], false, false)[0],
+                     __builtin_amdgcn_permlane32_swap(u[1], u[1], false, false)[0]};
+    return __builtin_bit_cast(double, o);
+}
+
 // byte offset of the 16-byte slot `slot` (0..3 = channels 8*slot .. 8*slot+7) of halo cell `cell` inside a piece image
 __device__ __forceinline__ int cell_slot_off(int cell, int slot) { return cell * 64 + ((slot ^ ((cell >> 2) & 3)) << 4); }
 
@@ -554,23 +577,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (stats) {
-        // BatchNorm partials of the STORED values: lanes that share a channel quad (same lane % LPR) are added by
-        // shuffles, the two row waves through LDS - a fixed order, run to run
+        // BatchNorm partials of the STORED values: lanes that share a channel quad (same lane % LPR) are added in the wave
+        // (partner8 / 16 / 32: the sum stands in lanes 48 .. 48 + LPR - 1), the row waves through LDS - a fixed order, run to run
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) {
-                ssum[q] += __shfl_xor(ssum[q], o, 64);
-                qsum[q] += __shfl_xor(qsum[q], o, 64);
+            if constexpr (LPR <= 8) {
+                ssum[q] += partner8(ssum[q]);
+                qsum[q] += partner8(qsum[q]);
             }
+            ssum[q] += partner16(ssum[q]);
+            qsum[q] += partner16(qsum[q]);
+            ssum[q] += partner32(ssum[q]);
+            qsum[q] += partner32(qsum[q]);
         }
         __syncthreads();   // every wave is done with its staging rows
         double* red = reinterpret_cast<double*>(smem);   // [wave][LPR * 4 channels][2]
-        if (lane < LPR) {
+        if (lane >= 48 && lane < 48 + LPR) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                red[((wave * LPR + lane) * 4 + q) * 2 + 0] = ssum[q];
-                red[((wave * LPR + lane) * 4 + q) * 2 + 1] = qsum[q];
+                red[((wave * LPR + lane - 48) * 4 + q) * 2 + 0] = ssum[q];
+                red[((wave * LPR + lane - 48) * 4 + q) * 2 + 1] = qsum[q];
             }
         }
         __syncthreads();
