@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     // on the 120x152 layers, whose blocks (54 MFMAs per wave) live on latency, not on the matrix pipe
     constexpr int HC = RECT ? (RCELLS + 31) / 32 * 32 : HCELLS;
     constexpr int HP = HC * 64;                        // bytes of one piece image
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HP + 2 * BTILE + CF_BYTES];   // ONE array
+    constexpr int RED_BYTES = (F16 || SBF) ? 4 * (CO == 128 ? 64 : 32) * 16 : 0;   // statistics: [wave][channels of a wave][2] fp64
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HP + 2 * BTILE + CF_BYTES + RED_BYTES];   // ONE array
     unsigned char* Aimg = smem;                        // [2 pieces][HC][64 B]
     unsigned char* Bimg = smem + 2 * HP;               // [2 buffers][BTILE]
     [[maybe_unused]] float* Cf = reinterpret_cast<float*>(smem + 2 * HP + 2 * BTILE);   // [3 planes][BN_NT][Cin]
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
             ssum[q] += partner32(ssum[q]);
             qsum[q] += partner32(qsum[q]);
         }
-        __syncthreads();   // every wave is done with its staging rows
-        double* red = reinterpret_cast<double*>(smem);   // [wave][LPR * 4 channels][2]
+        // (a region of its own, not the staging rows: no barrier until the partials are written)
+        double* red = reinterpret_cast<double*>(smem + 2 * HP + 2 * BTILE + CF_BYTES);   // [wave][LPR * 4 channels][2]
         if (lane >= 48 && lane < 48 + LPR) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
