@@ -390,8 +390,12 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
         // memory operations (at a control-flow join the compiler's wait-count pass falls back to vmcnt(0)), so it exists
         // in the two forms the layer-major step uses - BatchNorm affine, all T outputs, with / without a shortcut - and
         // everything else (no affine, last step only) takes the plain loop with its run-time checks.
-        auto time_loop = [&](auto piped_c, auto add_c, auto noout_c) {
-        constexpr bool PIPED = decltype(piped_c)::value;       // affine present, all outputs stored, ADD known
+        auto time_loop = [&](auto piped_c, auto add_c, auto noout_c, auto last_c) {
+        constexpr bool PIPED = decltype(piped_c)::value;       // affine present, ADD known, outputs: all steps or (LAST) one
+        // LAST (PIPED only; SNN_SCAN_LAST_STEP_ONLY, the detection heads' LI + Tanh): nothing is stored inside the loop, the
+        // last step's output once behind it - the plain loop below waited for every step's own loads, 32 dependent memory
+        // round trips (66 us for the 30x38 head at 2.9 TB/s)
+        constexpr bool LAST = decltype(last_c)::value;
         constexpr bool ADD = decltype(add_c)::value;
         // NOOUT (SNN_SCAN_SPIKES_FROM_VDEC; LIF without a shortcut, v_dec saved): no output tensor at all - the consumer
         // forms the spikes itself, z = (v_dec > v_th), while it reads the saved potentials (snn_conv1x1_spikes_*)
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 #pragma unroll
             for (int k = 0; k < kPrefetch; ++k) sq[k] = fetch_step(k);
         }
+        [[maybe_unused]] V o_keep;
         for (int t = 0; t < T; ++t) {
             const int64_t row = (int64_t)t * M + m;
             if (SAVE == 2 && NEURON == SNN_NEURON_LIF && (t % kCkpt) == 0) {
@@ -480,7 +485,9 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) lane<VEC>(o, j) += lane<VEC>(cur.ad, j);
             }
-            if constexpr (!NOOUT) {
+            if constexpr (LAST) {
+                o_keep = o;   // stored once behind the loop (no branch around a memory operation inside it)
+            } else if constexpr (!NOOUT) {
                 if (PIPED || !last_only) VecS<VEC, SB>::store(out, row * ldo + c, o);
                 else if (t == T - 1) VecS<VEC, SB>::store(out, m * ldo + c, o);
             }
@@ -491,18 +498,21 @@ __global__ __launch_bounds__(kThreads) void k_affine_neuron_fwd(
                 else VecS<VEC, SB>::store(vdec, row * C + c, vd);
             }
         }
+        if constexpr (LAST) VecS<VEC, SB>::store(out, m * ldo + c, o_keep);
         };
         if constexpr (VEC > 1 && SAVE != 2) {
             if (alpha && !last_only) {
-                if (addend) time_loop(std::true_type{}, std::true_type{}, std::false_type{});
+                if (addend) time_loop(std::true_type{}, std::true_type{}, std::false_type{}, std::false_type{});
                 else if (SAVE == 1 && NEURON == SNN_NEURON_LIF && !SB && out == nullptr)
-                    time_loop(std::true_type{}, std::false_type{}, std::true_type{});
-                else time_loop(std::true_type{}, std::false_type{}, std::false_type{});
+                    time_loop(std::true_type{}, std::false_type{}, std::true_type{}, std::false_type{});
+                else time_loop(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
+            } else if (alpha && last_only && !addend) {
+                time_loop(std::true_type{}, std::false_type{}, std::false_type{}, std::true_type{});
             } else {
-                time_loop(std::false_type{}, std::false_type{}, std::false_type{});
+                time_loop(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
             }
         } else {
-            time_loop(std::false_type{}, std::false_type{}, std::false_type{});
+            time_loop(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
         }
         if (NEURON != SNN_NEURON_NONE) {
             if (vT) Vec<VEC>::store(vT + m * C + c, v);
