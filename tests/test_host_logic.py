@@ -84,6 +84,17 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     assert hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) == (5 * 31 * 39 + 127) // 128
     assert hip_lib.snn_conv2d_fwd_bn_partial_size(160, 5, 30, 38, 128) >= 32 * hip_lib.snn_conv3x3_halo_bn_chunks(5, 30, 38) * 128 * 2
     assert hip_lib.snn_weight_frag_image_bytes(128, 64) == 9 * 128 * 64 * 4
+    # the reverse scan that rebuilds the BatchNorm statistic from the saved state: LIF, ordered-sums plans, fp32, all steps
+    from snn_for_object_detection_amd import functional as HF
+    prm = HF.neuron_params()
+    q = hip_lib.snn_affine_neuron_bwd_sums_from_state
+    assert q(_hip.NEURON_LIF, 32, 5 * 120 * 152, 64, 64, prm, 0) == 1
+    assert q(_hip.NEURON_LIF, 32, 5 * 120 * 152, 64, 128, prm, 0) == 1                    # g_out as a slice of a wider buffer
+    assert q(_hip.NEURON_LI, 32, 5 * 120 * 152, 64, 64, prm, 0) == 0                       # LIF only
+    assert q(_hip.NEURON_LIF, 32, 5 * 120 * 152, 64, 64, prm, _hip.SCAN_LAST_STEP_ONLY) == 0
+    assert q(_hip.NEURON_LIF, 32, 5 * 120 * 152, 64, 64, prm, _hip.SCAN_BF16_STORAGE) == 0  # a bf16 potential does not determine the input
+    assert q(_hip.NEURON_LIF, 32, 5 * 120 * 152, 24, 24, prm, 0) == 0                       # 6 channel quads: the LDS-atomics plan
+    assert q(_hip.NEURON_LIF, 32, 40_000_000, 64, 64, prm, 0) == 0                         # a timestep beyond the 31-bit buffer offsets
 
 
 def test_ctypes_signatures_agree_with_the_header():
