@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 10
+#define SNN_ABI_VERSION 11
 
 /* neuron kinds for the fused affine+neuron temporal scan */
 enum {
@@ -274,6 +274,27 @@ int snn_conv1x1_spikes_fwd(const float* vdec, int64_t ld, float v_th, const floa
                            int W, int Cin, int Cout, void* stream);
 int snn_conv1x1_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw, int64_t N,
                              int H, int W, int Cin, int Cout, int accumulate, float* workspace, int splitk, void* stream);
+
+/* The same for ANY convolution the pipelined implicit GEMM covers (KH, KW <= 5, Cin % 32 == 0, Cout % 4 == 0) - a plain
+ * `Conv -> Norm -> LIF -> Conv` stack (models/modules/layer_gen.py:106-136 / 211-235: the deep backbones of BASELINE
+ * configs[4]) writes no spike tensor between its layers:
+ *   snn_conv2d_spikes_fwd   : as snn_conv2d_fwd on z = (vdec > v_th), fp16 x 3 arithmetic with two products; bn_partial /
+ *                             frames_per_step / bn_layout as there
+ *   snn_conv2d_spikes_wgrad : as snn_conv2d_wgrad (workspace / splitk from snn_conv2d_wgrad_splitk, SNN_PREC_BF16X3); 3x3
+ *                             layers the halo-resident weight gradient covers take it (two products)
+ *   snn_conv3x3_halo_spikes : the halo-resident 3x3 / stride 1 / pad 1 forward (snn_conv3x3_halo, fp16 x 3 image) on the
+ *                             potentials; shapes: snn_conv3x3_halo_supported */
+int snn_conv2d_spikes_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                int pad, int64_t ld, int fwd_precision, int bwd_precision);
+int snn_conv2d_spikes_fwd(const float* vdec, int64_t ld, float v_th, const float* w, float* y, int64_t ldy, int64_t N, int H,
+                          int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, double* bn_partial,
+                          int frames_per_step, int* bn_layout, void* stream);
+int snn_conv2d_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw, int64_t N,
+                            int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                            int accumulate, float* workspace, int splitk, void* stream);
+int snn_conv3x3_halo_spikes(const float* vdec, int64_t ld, float v_th, const void* w_image, float* y, int64_t ldy, int64_t N,
+                            int H, int W, int Cin, int Cout, double* bn_partial, int frames_per_step, int* bn_layout,
+                            void* stream);
 
 /* ---------------------------------------------------------------- batch-norm statistics
  * Train-mode nn.BatchNorm2d (layer_gen.py:211-214) applied per TIMESTEP: for every (t,c)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 NEURON_NONE, NEURON_LIF, NEURON_LI, NEURON_LI_TANH, NEURON_SLI, NEURON_SYNAPSE = 0, 1, 2, 3, 4, 5
 POOL_AVG, POOL_MAX, POOL_SUM = 0, 1, 2
 ACT_RELU, ACT_SILU, ACT_TANH = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3, PREC_BF16X1, PREC_BF16S = 0, 1, 3, 4, 5, 6   # SNN_PREC_* of include/snn_hip.h
 SCAN_WIDE_ADDRESSING, SCAN_LAST_STEP_ONLY, SCAN_BF16_STORAGE, SCAN_SPIKES_FROM_VDEC, SCAN_SUMS_FROM_STATE = 1, 2, 4, 8, 16
 SCAN_STATE_LOOKBACK = 32
@@ -64,6 +64,10 @@ SIGNATURES = {
     "snn_conv1x1_spikes_supported": (c_int, [_L, _I, _I, _I, _I, _L, _I, _I]),
     "snn_conv1x1_spikes_fwd": (c_int, [_P, _L, _F, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
     "snn_conv1x1_spikes_wgrad": (c_int, [_P, _L, _F, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "snn_conv2d_spikes_supported": (c_int, [_L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I]),
+    "snn_conv2d_spikes_fwd": (c_int, [_P, _L, _F, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "snn_conv2d_spikes_wgrad": (c_int, [_P, _L, _F, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "snn_conv3x3_halo_spikes": (c_int, [_P, _L, _F, _P, _P, _L, _L, _I, _I, _I, _I, _P, _I, _P, _P]),
     "snn_bn_stats_partial_size": (c_size_t, [_I, _L, _I]),
     "snn_bn_stats": (c_int, [_P, _L, _I, _L, _I, _P, _P]),
     "snn_bn_stats_finalize": (c_int, [_P, _I, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P]),

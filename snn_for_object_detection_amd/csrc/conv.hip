@@ -2679,13 +2679,14 @@ static int wgrad_common(const float* x, int64_t ldx, const float* dy, int64_t ld
         SNN_CHECK_LAUNCH("snn_conv2d_wgrad");
         return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, splitk, accumulate, (hipStream_t)stream);
     }
-    if (bwd_split && !xsp) {
+    if (bwd_split) {
         const SnnWgradHaloPlan hp = snn_wgrad_halo_plan(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad);
         if (hp.ok) {
             SNN_REQUIRE(splitk == hp.slabs, "snn_conv2d_wgrad: splitk %d, expected %d (snn_conv2d_wgrad_splitk)", splitk,
                         hp.slabs);
             const int rc = snn_wgrad_halo_launch(hp, x, ldx, dy, lddy, workspace, N, H, W, Cin, Ho, Wo, Cout, stride,
-                                                 (precision == SNN_PREC_BF16X1 || sbf) ? 1 : 3, sbf, (hipStream_t)stream);
+                                                 xsp ? 2 : ((precision == SNN_PREC_BF16X1 || sbf) ? 1 : 3), sbf,
+                                                 (hipStream_t)stream, x_th);
             if (rc == 0)
                 return wgrad_reduce_slabs(workspace, dw, (int64_t)Cout * g.Ktot, hp.slabs, accumulate,
                                           (hipStream_t)stream);
@@ -2769,43 +2770,81 @@ extern "C" int snn_conv2d_wgrad(const float* x, int64_t ldx, const float* dy, in
                         precision, stream, false, 0.0f);
 }
 
-// ---- 1x1 convolutions over spikes that were never stored (see k_conv_gather XSP, include/snn_hip.h)
+// ---- convolutions over spikes that were never stored (see k_conv_gather XSP, include/snn_hip.h)
+static bool spikes_shape_ok(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                            int64_t ld) {
+    // the pipelined implicit GEMM (forward FAST path, pipelined weight gradient); 3x3 / stride 1 layers the halo-resident
+    // kernels cover take those instead (snn_conv3x3_halo_spikes, k_conv_wgrad_halo NPROD 2)
+    return N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH >= 1 && KW >= 1 && KH <= 5 && KW <= 5 && stride >= 1 &&
+           Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1 && Ho > 0 && Wo > 0 &&
+           Cin % 32 == 0 && Cout % 4 == 0 && ld % 4 == 0 && ld >= Cin && N * (int64_t)H * W < 0x7fffffffLL &&
+           N * (int64_t)Ho * Wo < 0x7fffffffLL && (int64_t)H * W * ld * 16 < 0x7fffffffLL;
+}
+
+extern "C" int snn_conv2d_spikes_supported(int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                           int stride, int pad, int64_t ld, int fwd_precision, int bwd_precision) {
+    return (fwd_precision == SNN_PREC_FP16X3 && bwd_precision == SNN_PREC_BF16X3 &&
+            spikes_shape_ok(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ld)) ? 1 : 0;
+}
+
 extern "C" int snn_conv1x1_spikes_supported(int64_t N, int H, int W, int Cin, int Cout, int64_t ld, int fwd_precision,
                                             int bwd_precision) {
-    return (N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 4 == 0 && ld % 4 == 0 && ld >= Cin &&
-            fwd_precision == SNN_PREC_FP16X3 && bwd_precision == SNN_PREC_BF16X3 && N * (int64_t)H * W < 0x7fffffffLL &&
-            (int64_t)H * W * ld * 16 < 0x7fffffffLL) ? 1 : 0;
+    return snn_conv2d_spikes_supported(N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, ld, fwd_precision, bwd_precision);
+}
+
+extern "C" int snn_conv2d_spikes_fwd(const float* vdec, int64_t ld, float v_th, const float* w, float* y, int64_t ldy,
+                                     int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                     int pad, double* bn_partial, int frames_per_step, int* bn_layout, void* stream) {
+    SNN_REQUIRE(vdec && w && y, "snn_conv2d_spikes_fwd: null pointer");
+    SNN_REQUIRE(v_th >= 0.0f, "snn_conv2d_spikes_fwd: a negative threshold would turn padding into spikes");
+    if (check_conv_shape("snn_conv2d_spikes_fwd", N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad)) return 1;
+    SNN_REQUIRE(spikes_shape_ok(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ld) && ldy >= Cout,
+                "snn_conv2d_spikes_fwd: shape not covered (ask snn_conv2d_spikes_supported)");
+    SNN_REQUIRE(!bn_partial || (bn_layout && frames_per_step > 0 && N % frames_per_step == 0),
+                "snn_conv2d_spikes_fwd: statistics need bn_layout and a frames_per_step that divides N");
+    if (bn_layout) bn_layout[0] = bn_layout[1] = 0;
+    ConvGeom g;
+    g.Mtot = N * Ho * (int64_t)Wo;
+    g.IH = H; g.IW = W; g.IC = Cin;
+    g.OH = Ho; g.OW = Wo; g.OC = Cout;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.ldi = ld; g.ldo = ldy;
+    g.Ktot = g.KtotFull = KH * KW * Cin;
+    g.nimg = (int)N;
+    g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = KH; g.nkw = KW; g.OHc = Ho; g.OWc = Wo;
+    g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(KW);
+    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
+    g.x_th = v_th;
+    const int64_t step_rows = bn_partial ? (int64_t)frames_per_step * Ho * Wo : 0;
+    if (bn_partial && step_rows >= BM && gather_bn_chunks(step_rows) <= 0x7fffffff) {
+        g.bn_partial = bn_partial;
+        g.bn_rows = step_rows;
+        g.bn_chunks = (int)gather_bn_chunks(step_rows);
+        bn_layout[0] = g.bn_chunks;
+        bn_layout[1] = BM;
+    }
+    return launch_gather<false, 4, false, true>(vdec, w, nullptr, y, g, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+                                                "snn_conv2d_spikes_fwd");
 }
 
 extern "C" int snn_conv1x1_spikes_fwd(const float* vdec, int64_t ld, float v_th, const float* w, float* y, int64_t ldy,
                                       int64_t N, int H, int W, int Cin, int Cout, void* stream) {
-    SNN_REQUIRE(vdec && w && y, "snn_conv1x1_spikes_fwd: null pointer");
-    SNN_REQUIRE(v_th >= 0.0f, "snn_conv1x1_spikes_fwd: a negative threshold would turn padding into spikes");
-    if (check_conv_shape("snn_conv1x1_spikes_fwd", N, H, W, Cin, H, W, Cout, 1, 1, 1, 0)) return 1;
-    SNN_REQUIRE(snn_conv1x1_spikes_supported(N, H, W, Cin, Cout, ld, SNN_PREC_FP16X3, SNN_PREC_BF16X3) && ldy >= Cout,
-                "snn_conv1x1_spikes_fwd: shape not covered (ask snn_conv1x1_spikes_supported)");
-    ConvGeom g;
-    g.Mtot = N * H * (int64_t)W;
-    g.IH = H; g.IW = W; g.IC = Cin;
-    g.OH = H; g.OW = W; g.OC = Cout;
-    g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0;
-    g.ldi = ld; g.ldo = ldy;
-    g.Ktot = g.KtotFull = Cin;
-    g.nimg = (int)N;
-    g.ph = g.pw = g.kh0 = g.kw0 = 0; g.nkh = 1; g.nkw = 1; g.OHc = H; g.OWc = W;
-    g.magic_ic = magic_u32(Cin); g.magic_kw = magic_u32(1);
-    g.bn_partial = nullptr; g.bn_rows = 0; g.bn_chunks = 0;
-    g.x_th = v_th;
-    return launch_gather<false, 4, false, true>(vdec, w, nullptr, y, g, nullptr, 0, nullptr, 0, (hipStream_t)stream,
-                                                "snn_conv1x1_spikes_fwd");
+    return snn_conv2d_spikes_fwd(vdec, ld, v_th, w, y, ldy, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int snn_conv2d_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw,
+                                       int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                                       int pad, int accumulate, float* workspace, int splitk, void* stream) {
+    SNN_REQUIRE(v_th >= 0.0f, "snn_conv2d_spikes_wgrad: a negative threshold would turn padding into spikes");
+    SNN_REQUIRE(spikes_shape_ok(N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ld),
+                "snn_conv2d_spikes_wgrad: shape not covered (ask snn_conv2d_spikes_supported)");
+    return wgrad_common(vdec, ld, dy, lddy, dw, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, accumulate, workspace, splitk,
+                        SNN_PREC_BF16X3, stream, true, v_th);
 }
 
 extern "C" int snn_conv1x1_spikes_wgrad(const float* vdec, int64_t ld, float v_th, const float* dy, int64_t lddy, float* dw,
                                         int64_t N, int H, int W, int Cin, int Cout, int accumulate, float* workspace,
                                         int splitk, void* stream) {
-    SNN_REQUIRE(v_th >= 0.0f, "snn_conv1x1_spikes_wgrad: a negative threshold would turn padding into spikes");
-    SNN_REQUIRE(snn_conv1x1_spikes_supported(N, H, W, Cin, Cout, ld, SNN_PREC_FP16X3, SNN_PREC_BF16X3),
-                "snn_conv1x1_spikes_wgrad: shape not covered (ask snn_conv1x1_spikes_supported)");
-    return wgrad_common(vdec, ld, dy, lddy, dw, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, accumulate, workspace, splitk,
-                        SNN_PREC_BF16X3, stream, true, v_th);
+    return snn_conv2d_spikes_wgrad(vdec, ld, v_th, dy, lddy, dw, N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, accumulate, workspace,
+                                   splitk, stream);
 }

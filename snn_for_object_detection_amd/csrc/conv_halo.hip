@@ -65,6 +65,7 @@ struct HaloGeom {
     int OH, OW;                 // k_conv_s2dgrad3 only: size of the produced tensor dx (the strip grid H x W is dy's)
     int bn_T, bn_tc, bn_fps;    // BNAP: timesteps, T * Cin (distance of the coefficient planes), frames per timestep
     int tiles_x, tiles_img;     // RECT: 4 x 32 pixel tiles per image row, tiles per image
+    float x_th;                 // XSP: x holds saved LIF potentials, the operand is z = (x > x_th)
 };
 
 __device__ __forceinline__ unsigned udiv_small(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -141,7 +142,11 @@ constexpr int RTH = 4, RTW = 32, RPITCH = RTW + 2, RCELLS = (RTH + 2) * RPITCH;
 // the bf16 image itself (8-byte loads, no split: ONE piece), the weight image's high pieces are the bf16-rounded weights
 // (the low pieces are neither copied nor multiplied): one MFMA product per multiply-add; results are rounded to bf16 in
 // the epilogue (the BatchNorm partials are taken from the fp32 values before that rounding).
-template <int CO, bool F16, int ABL = 0, bool BNAP = false, bool RECT = false, bool SBF = false>
+// XSP (snn_conv3x3_halo_spikes; forward only): x holds the pre-reset potentials a LIF layer saved for its backward pass, NOT
+// its spikes - that layer wrote no spike tensor (SNN_SCAN_SPIKES_FROM_VDEC) - and the operand z = (v_dec > x_th) is formed while
+// the halo goes to LDS: ONE exact fp16 piece (1.0 x 2^4 or 0), no low image, the product low(x) * high(w) is not issued (two
+// MFMA products instead of three).  Same bits as the plain kernel on the stored spikes, whose low pieces are zeros.
+template <int CO, bool F16, int ABL = 0, bool BNAP = false, bool RECT = false, bool SBF = false, bool XSP = false>
 __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restrict__ x,
                                                            const unsigned char* __restrict__ wimg,
                                                            float* __restrict__ y, HaloGeom g,
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
     constexpr int NDMA = (CO / 32) * 4 / 4;     // 1-KiB LDS-DMA pieces per wave and k-step
     constexpr int ES = SBF ? 2 : 4;             // bytes per activation element in HBM
     static_assert(!SBF || (!F16 && !BNAP && ABL == 0), "bf16 storage: bf16 MFMA, plain variant");
+    static_assert(!XSP || (F16 && !BNAP && !SBF && ABL == 0), "spikes from potentials: the forward arithmetic, plain variant");
     constexpr int CF_BYTES = BNAP ? 3 * BN_NT * BN_CMAX * 4 : 0;
     // cells the LDS halo image holds: a rectangle tile's halo is 6 x 34 = 204 cells (7 staging passes), not the 288 of the
     // widest strip tile - 37 instead of 45 KiB of LDS for the 32-channel instance, i.e. FOUR instead of three blocks per CU
@@ -325,6 +331,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                 if (p * 32 >= HC) continue;   // passes past the rectangle's halo (all their cells are out of range)
             if constexpr (SBF) {
                 *reinterpret_cast<u32x2*>(Aimg + awr[p]) = pf[p];
+            } else if constexpr (XSP) {   // fp16 16.0 = 0x4C00: the spike times the activation pre-scale
+                const u32x2 hi = {(pf[p][0] > g.x_th ? 0x4C00u : 0u) | (pf[p][1] > g.x_th ? 0x4C000000u : 0u),
+                                  (pf[p][2] > g.x_th ? 0x4C00u : 0u) | (pf[p][3] > g.x_th ? 0x4C000000u : 0u)};
+                *reinterpret_cast<u32x2*>(Aimg + awr[p]) = hi;
             } else {
                 u32x2 hi, lo;
                 split4<F16>(pf[p], hi, lo);
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                     continue;
                 }
                 ah[i] = *reinterpret_cast<const bf16x8*>(Aimg + off);
-                if constexpr (!SBF) al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HP + off);
+                if constexpr (!SBF && !XSP) al[i] = *reinterpret_cast<const bf16x8*>(Aimg + HP + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -388,6 +398,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_halo3(const float* __restr
                 for (int j = 0; j < TN; ++j) {   // small terms first
                     if constexpr (SBF) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    } else if constexpr (XSP) {
+                        const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]);
+                        const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah, xbh, acc[i][j], 0, 0, 0);
                     } else if constexpr (F16) {
                         const f16x8 xah = __builtin_bit_cast(f16x8, ah[i]), xal = __builtin_bit_cast(f16x8, al[i]);
                         const f16x8 xbh = __builtin_bit_cast(f16x8, bh[j]), xbl = __builtin_bit_cast(f16x8, bl[j]);
@@ -1003,6 +1018,7 @@ extern "C" int snn_conv3x3_s2_dgrad(const float* dy, int64_t lddy, const void* w
     g.out_vec = (lddx % 4 == 0) && out_aligned(dx, sbf) && (!addend || (ld_addend % 4 == 0 && out_aligned(addend, sbf))) &&
                 (!addend2 || (ld_addend2 % 4 == 0 && out_aligned(addend2, sbf)));
     g.bn_partial = nullptr;
+    g.x_th = 0.0f;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     const unsigned char* wi = static_cast<const unsigned char*>(wt_image);
@@ -1090,6 +1106,7 @@ extern "C" int snn_conv3x3_halo_bn(const float* gx, const float* y, const float*
     g.out_vec = (lddx % 4 == 0) && aligned16(dx) && (!addend || (ld_addend % 4 == 0 && aligned16(addend))) &&
                 (!addend2 || (ld_addend2 % 4 == 0 && aligned16(addend2)));
     g.bn_partial = nullptr;
+    g.x_th = 0.0f;
     g.OH = H; g.OW = W;
     g.bn_fps = frames_per_step; g.bn_T = (int)(N / frames_per_step); g.bn_tc = g.bn_T * Cin;
     g.tiles_x = g.tiles_img = 0;
@@ -1105,10 +1122,10 @@ extern "C" int snn_conv3x3_halo_bn(const float* gx, const float* y, const float*
     return 0;
 }
 
-extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image, float* y, int64_t ldy, int64_t N, int H,
-                                int W, int Cin, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
-                                int64_t ld_addend2, double* bn_partial, int frames_per_step, int* bn_layout,
-                                int precision, void* stream) {
+static int conv3x3_halo_impl(const float* x, int64_t ldx, const void* w_image, float* y, int64_t ldy, int64_t N, int H,
+                             int W, int Cin, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
+                             int64_t ld_addend2, double* bn_partial, int frames_per_step, int* bn_layout,
+                             int precision, void* stream, bool xsp, float x_th) {
     SNN_REQUIRE(x && w_image && y, "snn_conv3x3_halo: null pointer");
     SNN_REQUIRE(precision == SNN_PREC_FP16X3 || precision == SNN_PREC_BF16X3 || precision == SNN_PREC_BF16S,
                 "snn_conv3x3_halo: precision must be SNN_PREC_FP16X3, SNN_PREC_BF16X3 or SNN_PREC_BF16S (got %d)", precision);
@@ -1159,6 +1176,7 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
     g.bn_partial = bn_partial;
     g.OH = H; g.OW = W;
     g.bn_T = g.bn_tc = 0; g.bn_fps = 1;
+    g.x_th = x_th;
     if (bn_partial) bn_layout[0] = g.tiles_per_group;   // every slot of every step is written: rows_per_chunk stays 0
     dim3 grid((unsigned)((int64_t)g.tiles_per_xcd * 8 * g.ntiles_n));
     const unsigned char* wi = static_cast<const unsigned char*>(w_image);
@@ -1185,6 +1203,23 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
 #undef SNN_HALO_ABL_LAUNCH
     }
 #endif
+    if (xsp) {   // (precision checked by the caller: the forward arithmetic)
+#define SNN_HALO_LAUNCH_X(CO_)                                                                                       \
+    do {                                                                                                              \
+        if (rect)                                                                                                     \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, true, 0, false, true, false, true>), grid, dim3(kThreads), 0,          \
+                               (hipStream_t)stream, x, wi, y, g, addend, addend2, nullptr, nullptr, nullptr);          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_conv_halo3<CO_, true, 0, false, false, false, true>), grid, dim3(kThreads), 0,         \
+                               (hipStream_t)stream, x, wi, y, g, addend, addend2, nullptr, nullptr, nullptr);          \
+    } while (0)
+        if (co_tile == 128) SNN_HALO_LAUNCH_X(128);
+        else if (co_tile == 64) SNN_HALO_LAUNCH_X(64);
+        else SNN_HALO_LAUNCH_X(32);
+#undef SNN_HALO_LAUNCH_X
+        SNN_CHECK_LAUNCH("snn_conv3x3_halo_spikes");
+        return 0;
+    }
     if (sbf) {
 #define SNN_HALO_LAUNCH_S(CO_)                                                                                       \
     do {                                                                                                              \
@@ -1212,4 +1247,21 @@ extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image
 #undef SNN_HALO_LAUNCH
     SNN_CHECK_LAUNCH("snn_conv3x3_halo");
     return 0;
+}
+
+extern "C" int snn_conv3x3_halo(const float* x, int64_t ldx, const void* w_image, float* y, int64_t ldy, int64_t N, int H,
+                                int W, int Cin, int Cout, const float* addend, int64_t ld_addend, const float* addend2,
+                                int64_t ld_addend2, double* bn_partial, int frames_per_step, int* bn_layout,
+                                int precision, void* stream) {
+    return conv3x3_halo_impl(x, ldx, w_image, y, ldy, N, H, W, Cin, Cout, addend, ld_addend, addend2, ld_addend2, bn_partial,
+                             frames_per_step, bn_layout, precision, stream, false, 0.0f);
+}
+
+// forward over spikes that were never stored (k_conv_halo3 XSP): `vdec` holds the potentials, w_image the fp16 x 3 image
+extern "C" int snn_conv3x3_halo_spikes(const float* vdec, int64_t ld, float v_th, const void* w_image, float* y, int64_t ldy,
+                                       int64_t N, int H, int W, int Cin, int Cout, double* bn_partial, int frames_per_step,
+                                       int* bn_layout, void* stream) {
+    SNN_REQUIRE(v_th >= 0.0f, "snn_conv3x3_halo_spikes: a negative threshold would turn padding into spikes");
+    return conv3x3_halo_impl(vdec, ld, w_image, y, ldy, N, H, W, Cin, Cout, nullptr, 0, nullptr, 0, bn_partial,
+                             frames_per_step, bn_layout, SNN_PREC_FP16X3, stream, true, v_th);
 }

@@ -69,7 +69,7 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
                           int nprod /* 3: bf16 x 3, 1: bf16 x 1 */, bool bf16_storage /* x, dy bf16 (nprod 1) */,
-                          hipStream_t st);
+                          hipStream_t st, float x_th = 0.0f);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -69,6 +69,7 @@ struct HaloGeom {
     int Ktot;                      // 9 * Cin
     unsigned m_cw, m_hc, m_ppi, m_npc;  // ceil(2^32 / d): q = umulhi(n, m) for n * d < 2^32
     int ablate;                         // tuning builds only: bit 0 drops the dy loads, bit 1 the x loads (timing aid)
+    float x_th;                         // NPROD 2: x holds saved LIF potentials, the operand is z = (v_dec > x_th)
 };
 
 static unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
@@ -85,6 +86,10 @@ __device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsig
 
 // SB (bf16-storage mode, NPROD 1): x and dy are bf16 tensors - the halo goes to LDS as it arrives, the dy fragment is
 // eight 2-byte loads; nothing is converted.
+// NPROD 2 (snn_conv2d_spikes_wgrad): x holds the pre-reset potentials a LIF layer saved for its backward pass, NOT its spikes -
+// that layer wrote no spike tensor (SNN_SCAN_SPIKES_FROM_VDEC) - and the operand z = (v_dec > x_th) is formed while the halo
+// is written to LDS: one exact bf16 piece (1.0 or 0), no low image, the product high(dy) * low(x) is not issued.  Same bits
+// as NPROD 3 fed the stored spikes.
 template <int WCO, int WK, int S, int NPROD, bool SB = false>   // NPROD: 3 = bf16 x 3 (hi + lo pieces), 1 = bf16 x 1 (hi pieces only)
 __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
@@ -179,6 +184,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
             if constexpr (SB) {
                 h0 = st[j][0];
                 h1 = st[j][1];
+            } else if constexpr (NPROD == 2) {   // spikes from potentials: bf16 1.0 = 0x3F80
+                h0 = (st[j][0] > g.x_th ? 0x3F80u : 0u) | (st[j][1] > g.x_th ? 0x3F800000u : 0u);
+                h1 = (st[j][2] > g.x_th ? 0x3F80u : 0u) | (st[j][3] > g.x_th ? 0x3F800000u : 0u);
             } else {
                 split_bf16(st[j][0], st[j][1], h0, l0);
                 split_bf16(st[j][2], st[j][3], h1, l1);
@@ -299,6 +307,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv_wgrad_halo(const float* __
                     const bf16x8 Bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fl[u][0], fl[u][1], 0, 1, 2, 3, 4, 5, 6, 7));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);  // small terms first
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
+                } else if constexpr (NPROD == 2) {   // the low image of a spike is zero
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
             }
@@ -443,7 +453,7 @@ SnnWgradHaloPlan snn_wgrad_halo_plan(int64_t N, int H, int W, int Cin, int Ho, i
 
 int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx, const float* dy, int64_t lddy,
                           float* workspace, int64_t N, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride,
-                          int nprod, bool bf16_storage, hipStream_t st) {
+                          int nprod, bool bf16_storage, hipStream_t st, float x_th) {
     // 32-bit byte offsets inside one image (buffer addressing)
     if ((int64_t)H * W * ldx * 4 >= 0x7fffffffLL || (int64_t)Ho * Wo * lddy * 4 >= 0x7fffffffLL) return -1;
     if (ldx % 4 != 0 || !(bf16_storage ? aligned8(x) : aligned16(x))) return -1;
@@ -458,6 +468,7 @@ int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx
     g.tiles_co = p.tiles_co; g.tiles_ci = p.tiles_ci; g.splits = p.splits;
     g.Ktot = 9 * Cin;
     g.ablate = snn_tuning_env("SNN_HALO_ABLATE") ? atoi(snn_tuning_env("SNN_HALO_ABLATE")) : 0;
+    g.x_th = x_th;
     g.m_cw = magic_u32(g.CW); g.m_hc = magic_u32(g.HC); g.m_ppi = magic_u32(g.ppi); g.m_npc = magic_u32(g.npc);
     const int64_t nblocks = (int64_t)p.tiles_co * p.tiles_ci * p.splits;
     if (nblocks > 0x7fffffffLL) return -1;
@@ -468,6 +479,10 @@ int snn_wgrad_halo_launch(const SnnWgradHaloPlan& p, const float* x, int64_t ldx
             hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
         else if (bf16_storage)                                                                                      \
             hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 1, true>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (stride == 1 && nprod == 2)                                                                         \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 2>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
+        else if (nprod == 2)                                                                                        \
+            hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 2, 2>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
         else if (stride == 1 && nprod == 3)                                                                         \
             hipLaunchKernelGGL((k_conv_wgrad_halo<WCO_, WK_, 1, 3>), grid, dim3(kThreads), 0, st, x, dy, workspace, g); \
         else if (nprod == 3)                                                                                        \

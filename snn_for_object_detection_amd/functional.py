@@ -749,7 +749,9 @@ class _Conv2d(Function):
     """nn.Conv2d(bias=False, padding=int(k/2), stride) over all T*B frames (layer_gen.py:129-136)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None, bn_out=None):
+    def forward(ctx, x, weight, stride: int, pad: int, slot=None, dest=None, acc=None, prec=None, bn_out=None, x_th=None):
+        # x_th (a float): x holds the saved POTENTIALS of a LIF layer that wrote no spike tensor; the operand is
+        # z = (x > x_th), formed by the kernels while they read (snn_conv2d_spikes_* / snn_conv3x3_halo_spikes)
         _require_device(x, "conv2d input", bf16_ok=True)
         fwd_prec, bwd_prec = prec if prec is not None else _prec_codes(None, None)
         _require_device(weight, "conv2d weight")
@@ -764,6 +766,11 @@ class _Conv2d(Function):
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
         x = _raw_to_cl(x)
+        if x_th is not None and (sb or not _hip.query("snn_conv2d_spikes_supported", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW,
+                                                       stride, pad, cl_stride(x), fwd_prec, bwd_prec)):
+            # arithmetic or shape the thresholding kernels do not cover: the spikes are written after all
+            x = _cl_view((x.permute(0, 1, 3, 4, 2) > x_th).to(_F32).contiguous())
+            x_th = None
         w = weight.detach()
         w_ohwi = w if is_channels_last(w) else _raw_dense_cl(w)
         y = _out_tensor(dest, T, B, Cout, Ho, Wo, x, _BF16 if sb else None)
@@ -786,8 +793,15 @@ class _Conv2d(Function):
                 img = None
             if img is None:
                 img = _frag_image(w_ohwi, Cout, Cin, 0, img_prec)
-            _hip.call("snn_conv3x3_halo", x.data_ptr(), cl_stride(x), img.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
-                      H, W, Cin, Cout, None, 0, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
+            if x_th is not None:
+                _hip.call("snn_conv3x3_halo_spikes", x.data_ptr(), cl_stride(x), x_th, img.data_ptr(), y.data_ptr(),
+                          cl_stride(y), T * B, H, W, Cin, Cout, _ptr(partial), B, layout, _stream())
+            else:
+                _hip.call("snn_conv3x3_halo", x.data_ptr(), cl_stride(x), img.data_ptr(), y.data_ptr(), cl_stride(y), T * B,
+                          H, W, Cin, Cout, None, 0, None, 0, _ptr(partial), B, layout, fwd_prec, _stream())
+        elif x_th is not None:
+            _hip.call("snn_conv2d_spikes_fwd", x.data_ptr(), cl_stride(x), x_th, w_ohwi.data_ptr(), y.data_ptr(), cl_stride(y),
+                      T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, _ptr(partial), B, layout, _stream())
         else:
             _hip.call("snn_conv2d_fwd", x.data_ptr(), cl_stride(x), w_ohwi.data_ptr(), w16, y.data_ptr(), cl_stride(y),
                       T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, None, 0, _ptr(partial), B, layout, fwd_prec,
@@ -795,6 +809,7 @@ class _Conv2d(Function):
         if layout is not None and layout[0] > 0:
             bn_out.append(BnPartial(partial, int(layout[0]), int(layout[1]), y.data_ptr(), (T, B * Ho * Wo, Cout)))
         ctx.prec = bwd_prec
+        ctx.x_th = x_th
         ctx.save_for_backward(x, w_ohwi)
         ctx.weight_ref = weight if getattr(weight, "_snn_wt", None) is not None else None  # FlatTrainer's cached w^T
         ctx.geom = (T, B, Cin, H, W, Cout, KH, KW, Ho, Wo, stride, pad)
@@ -831,7 +846,7 @@ class _Conv2d(Function):
                               Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk, stream.cuda_stream)
                 if on_side:
                     _side_hold(stream, x, pend.gx, pend.y, pend.coef)
-                return None, None, None, None, None, None, None, None, None
+                return None, None, None, None, None, None, None, None, None, None
             fused_dgrad = (ctx.needs_input_grad[0] and ctx.prec == _hip.PREC_BF16X3 and USE_HALO_CONV
                            and (KH, KW, stride, pad) == (3, 3, 1, 1) and pend.dims == (T, B, Cout, Ho, Wo)
                            and is_channels_last(pend.y)
@@ -861,6 +876,14 @@ class _Conv2d(Function):
                 dx = _dgrad_accumulate(ctx.acc, gy, ldg, wt, x, ctx.geom, st, ctx.prec, wt_split=wt16, wt_image=wt_img)
         if ctx.needs_input_grad[1]:
             splitk = _hip.query("snn_conv2d_wgrad_splitk", T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.prec)
+
+            def wgrad(dst_ptr, accumulate, ws_, stream_ptr):
+                if ctx.x_th is not None:   # x holds potentials: thresholded on load
+                    _hip.call("snn_conv2d_spikes_wgrad", x.data_ptr(), ldx, ctx.x_th, gy.data_ptr(), ldg, dst_ptr, T * B, H,
+                              W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, accumulate, ws_.data_ptr(), splitk, stream_ptr)
+                else:
+                    _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dst_ptr, T * B, H, W, Cin, Ho, Wo,
+                              Cout, KH, KW, stride, pad, accumulate, ws_.data_ptr(), splitk, ctx.prec, stream_ptr)
             if ctx.slot is not None and _wgrad_on_side():
                 # gradient goes straight into the flat buffer: nothing downstream in autograd needs it, so
                 # the kernel runs on the side stream, concurrently with the data-gradient chain
@@ -869,22 +892,17 @@ class _Conv2d(Function):
                 side.wait_stream(main)  # gy (and every earlier use of the slot) is complete
                 with torch.cuda.stream(side):
                     ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
-                    _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(),
-                              T * B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(),
-                              splitk, ctx.prec, side.cuda_stream)
+                    wgrad(ctx.slot.buf.data_ptr(), ctx.slot.claim(), ws, side.cuda_stream)
                 _side_hold(side, x, gy)
             elif ctx.slot is not None:
                 ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
-                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, ctx.slot.buf.data_ptr(), T * B,
-                          H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ctx.slot.claim(), ws.data_ptr(), splitk,
-                          ctx.prec, st)
+                wgrad(ctx.slot.buf.data_ptr(), ctx.slot.claim(), ws, st)
             else:
                 ws = torch.empty((splitk, Cout * KH * KW * Cin), device=x.device, dtype=_F32)
                 dw_ohwi = torch.empty((Cout, KH, KW, Cin), device=x.device, dtype=_F32)
-                _hip.call("snn_conv2d_wgrad", x.data_ptr(), ldx, gy.data_ptr(), ldg, dw_ohwi.data_ptr(), T * B, H,
-                          W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, 0, ws.data_ptr(), splitk, ctx.prec, st)
+                wgrad(dw_ohwi.data_ptr(), 0, ws, st)
                 dw = dw_ohwi.permute(0, 3, 1, 2)
-        return dx, dw, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None
 
 
 def _small_gemm(a: torch.Tensor, trans_a: bool, b: torch.Tensor, trans_b: bool, c: torch.Tensor, accumulate: int,
@@ -1229,10 +1247,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
         # prediction head applied to every timestep - take the fp32 kernels between two conversions
         y = to_bfloat16(conv2d(to_float32(x), weight, stride, padding, None, forward_precision, backward_precision, False))
         return place(y, dest) if dest is not None else y
+    x_th = getattr(x, "_snn_spike_threshold", None)   # x holds a LIF layer's saved potentials (affine_neuron spikes_ok)
     seq, single = as_sequence(x)
     bn_out = [] if bn_stats else None
     y = _Conv2d.apply(seq, weight, int(stride), int(padding), _slot_of(weight), dest, _acc_of(seq),
-                      _prec_codes(forward_precision, backward_precision), bn_out)
+                      _prec_codes(forward_precision, backward_precision), bn_out, x_th)
     y = y[0] if single else y
     if bn_out:
         y._snn_bn_partial = bn_out[0]

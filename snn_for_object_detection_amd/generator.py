@@ -319,10 +319,17 @@ class BlockGen(nn.Module):
                                  and not (isinstance(holder, StateStorage) and not self.training))
                     # the only consumer is the fused sibling convolution of the next block (the stage-entry Conv -> Norm -> LIF
                     # in front of a C2f split): it can form the spikes from the saved potentials, none are written
+                    # ... or a plain convolution (a Conv -> Norm -> LIF -> Conv stack: the deep backbones): HF.conv2d thresholds on
+                    # load where its kernels cover the shape and writes the spikes itself where they do not
+                    nxt_l = branch[plan[k + 1][1]] if (not last and plan[k + 1][0] == "layer") else None
                     spikes_ok = (zero_copy and not last and self.training and neuron == _hip.NEURON_LIF
                                  and direct is None and shortcut is None and not isinstance(holder, StateStorage)
-                                 and plan[k + 1][0] == "conv_block" and branch[plan[k + 1][1] + 1]._siblings is not None
-                                 and HF.USE_SIBLING_FUSION and HF.USE_SPIKES_FROM_VDEC)
+                                 and HF.USE_SPIKES_FROM_VDEC
+                                 and ((plan[k + 1][0] == "conv_block" and branch[plan[k + 1][1] + 1]._siblings is not None
+                                       and HF.USE_SIBLING_FUSION)
+                                      or (isinstance(nxt_l, HipConv2d) and nxt_l.in_channels % 32 == 0
+                                          and nxt_l.out_channels % 4 == 0 and nxt_l.kernel_size[0] <= 5
+                                          and nxt_l.forward_precision is None and nxt_l.backward_precision is None)))
                     Y, new = HF.affine_neuron(Y, neuron, old, bn=layer, params=cell.params, dest=direct,
                                               addend=shortcut, last_only=only_last, spikes_ok=spikes_ok)
                     if isinstance(holder, StateStorage):

@@ -309,3 +309,124 @@ def test_three_sibling_branches_and_bf16_storage(S):
     assert rel_err(yb.float(), yp.float()) < 1e-2 and rel_err(yb.float(), y0) < 5e-2
     for k in g0:
         assert rel_err(gb[k], gp[k]) < 5e-2, k
+
+
+SPIKE_CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride       what runs (forward / weight gradient)
+    (6, 30, 38, 128, 128, 3, 1),          # halo-resident strip tiles, 128-wide / implicit GEMM (below the halo wgrad's size)
+    (140, 30, 38, 64, 64, 3, 1),          # ... 64-wide / halo-resident weight gradient (two products)
+    (3, 24, 100, 64, 64, 3, 1),           # rectangles (rows longer than 78 pixels)
+    (90, 40, 44, 32, 32, 3, 1),           # the 32-channel tile / halo-resident weight gradient, K-steps split over the waves
+    (330, 37, 52, 64, 128, 3, 2),         # stride 2: implicit GEMM forward, halo-resident weight gradient (de-interleaved halo)
+    (4, 17, 23, 32, 48, 5, 1),            # 5x5: implicit GEMM both ways
+    (5, 12, 19, 96, 36, 3, 1),            # 36 output channels: no halo tile, implicit GEMM
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", SPIKE_CONV_CASES)
+def test_spike_convolutions_of_any_kernel_size_equal_the_plain_kernels_on_stored_spikes(hip_lib, N, H, W, Cin, Cout, k, s):
+    """snn_conv2d_spikes_fwd / snn_conv3x3_halo_spikes / snn_conv2d_spikes_wgrad (a LIF layer in front of a PLAIN convolution
+    writes no spike tensor either): bit for bit the plain kernels on the stored spikes, statistics partials included."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import ctypes
+    from snn_for_object_detection_amd import _hip
+    g = torch.Generator().manual_seed(N + H + Cin)
+    v_th, pad = 1.0, k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    vdec = (1.0 + 0.8 * torch.randn(N, H, W, Cin, generator=g)).cuda()
+    vdec[0, 0, 0, :4] = torch.tensor([1.0, 1.0 + 2 ** -23, 1.0 - 2 ** -24, 0.0])
+    z = (vdec > v_th).float()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).cuda()
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    assert _hip.query("snn_conv2d_spikes_supported", N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, Cin, _hip.PREC_FP16X3,
+                      _hip.PREC_BF16X3)
+    B = N // 2 if N % 2 == 0 else N          # frames per "timestep" of the statistics
+    n_part = _hip.query("snn_conv2d_fwd_bn_partial_size", N, B, Ho, Wo, Cout)
+    outs = []
+    halo = (k, s) == (3, 1) and _hip.query("snn_conv3x3_halo_supported", N, H, W, Cin, Cout)
+    for spikes in (False, True):
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+        part = torch.zeros(max(n_part, 1), device="cuda", dtype=torch.float64)
+        lay = (ctypes.c_int * 2)()
+        pp = part.data_ptr() if n_part else None
+        if halo:
+            img = torch.empty(9 * Cout * Cin, device="cuda")
+            table = torch.tensor([[0, 0, Cout, Cin]], dtype=torch.int64, device="cuda")
+            _hip.call("snn_weight_frag_image_batched", w.data_ptr(), img.data_ptr(), table.data_ptr(), 1,
+                      9 * (Cin // 32) * (Cout // 32) * 128, 0, _hip.PREC_FP16X3, st)
+            if spikes:
+                _hip.call("snn_conv3x3_halo_spikes", vdec.data_ptr(), Cin, v_th, img.data_ptr(), y.data_ptr(), Cout, N, H, W,
+                          Cin, Cout, pp, B, lay, st)
+            else:
+                _hip.call("snn_conv3x3_halo", z.data_ptr(), Cin, img.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Cout, None,
+                          0, None, 0, pp, B, lay, _hip.PREC_FP16X3, st)
+        elif spikes:
+            _hip.call("snn_conv2d_spikes_fwd", vdec.data_ptr(), Cin, v_th, w.data_ptr(), y.data_ptr(), Cout, N, H, W, Cin, Ho,
+                      Wo, Cout, k, k, s, pad, pp, B, lay, st)
+        else:
+            _hip.call("snn_conv2d_fwd", z.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, N, H, W, Cin, Ho, Wo, Cout,
+                      k, k, s, pad, None, 0, pp, B, lay, _hip.PREC_FP16X3, st)
+        outs.append((y, part, (lay[0], lay[1])))
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][2] == outs[1][2] and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.conv2d(z.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), stride=s,
+                                     padding=pad).permute(0, 2, 3, 1)
+    assert rel_err(outs[1][0], ref) < 2e-6
+    splitk = _hip.query("snn_conv2d_wgrad_splitk", N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, _hip.PREC_BF16X3)
+    ws = torch.empty(splitk, Cout * k * k * Cin, device="cuda")
+    g_ref, g_new = torch.empty(Cout, k, k, Cin, device="cuda"), torch.full((Cout, k, k, Cin), 0.25, device="cuda")
+    _hip.call("snn_conv2d_wgrad", z.data_ptr(), Cin, dy.data_ptr(), Cout, g_ref.data_ptr(), N, H, W, Cin, Ho, Wo, Cout, k, k, s,
+              pad, 0, ws.data_ptr(), splitk, _hip.PREC_BF16X3, st)
+    _hip.call("snn_conv2d_spikes_wgrad", vdec.data_ptr(), Cin, v_th, dy.data_ptr(), Cout, g_new.data_ptr(), N, H, W, Cin, Ho,
+              Wo, Cout, k, k, s, pad, 1, ws.data_ptr(), splitk, st)
+    assert torch.equal(g_new, g_ref + 0.25)
+
+
+def test_plain_convolution_stack_writes_no_spike_tensor_between_its_layers(S):
+    """Conv -> Norm -> LIF -> Conv -> Norm -> LIF -> Conv (the deep backbones of BASELINE configs[4]): with
+    USE_SPIKES_FROM_VDEC the hidden LIF layers write potentials only and the next convolution thresholds on load - outputs and
+    every gradient bit for bit those of the path that stores the spikes."""
+    from snn_for_object_detection_amd import _hip
+    HF = S.functional
+    T, B, H, W, c = 4, 2, 36, 44, 64
+    torch.manual_seed(7)
+    cfg = [S.Conv(c, 3, 2), S.Norm(), S.LIF(), S.Conv(c, 3), S.Norm(), S.LIF(), S.Conv(c, 5), S.Norm(), S.LIF(),
+           S.Conv(2 * c, 3, 2), S.Norm(), S.LIF()]
+    blk = S.BlockGen(2, [cfg]).cuda().train()
+    x = synthetic_events(T, B, H, W, p=0.3, seed=1).cuda()
+    probe = torch.randn(T, B, 2 * c, H // 4, W // 4, generator=torch.Generator().manual_seed(4)).cuda()
+
+    def run(on):
+        was = HF.USE_SPIKES_FROM_VDEC
+        HF.USE_SPIKES_FROM_VDEC = on
+        calls = []
+
+        class Spy:
+            def before(self, name, args):
+                calls.append((name, args))
+
+            def after(self, tok):
+                pass
+        _hip.PROFILER = Spy()
+        try:
+            blk.zero_grad(set_to_none=True)
+            y, _ = blk(x)
+            (y * probe).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().clone(), {k: p.grad.detach().clone() for k, p in blk.named_parameters()}, calls
+        finally:
+            _hip.PROFILER = None
+            HF.USE_SPIKES_FROM_VDEC = was
+    y1, g1, calls1 = run(True)
+    y0, g0, calls0 = run(False)
+    assert float(y0.abs().sum()) > 0 and torch.equal(y1, y0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    names1, names0 = [nm for nm, _ in calls1], [nm for nm, _ in calls0]
+    assert names1.count("snn_conv3x3_halo_spikes") + names1.count("snn_conv2d_spikes_fwd") == 3
+    assert names1.count("snn_conv2d_spikes_wgrad") == 3
+    assert not any("spikes" in nm for nm in names0)
+    no_out = [a for nm, a in calls1 if nm == "snn_affine_neuron_fwd" and a[7] is None]
+    assert len(no_out) == 3 and all(a[18] & _hip.SCAN_SPIKES_FROM_VDEC for a in no_out)   # the last LIF feeds nobody here
