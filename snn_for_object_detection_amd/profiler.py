@@ -87,6 +87,21 @@ def work_of(name: str, a):
             return WGRAD_LABELS[0], flops, byts
         tile = "32, 4, 1" if cout <= 32 else ("64, 2, 2" if cout <= 64 else "128, 2, 2")
         return f"k_conv_gather<{tile}, false, true>", flops, byts
+    if name in ("snn_conv2d_spikes_fwd", "snn_conv2d_spikes_wgrad"):   # any kernel size over spikes formed from saved potentials
+        # (vdec, ld, v_th, w | dy, y | lddy, ldy | dw, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ...)
+        fwd = name.endswith("_fwd")
+        n, h, w, cin, ho, wo, cout, kh, kw, stride, pad = a[6:17]
+        flops = 2.0 * n * ho * wo * cout * kh * kw * cin
+        byts = 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * kh * kw * cin)
+        if not fwd:
+            return _wgrad_label(n, h, w, cin, ho, wo, cout, kh, kw, stride, pad, 1) + ", spikes", flops, byts
+        tile = "32, 4, 1" if cout <= 32 else ("64, 2, 2" if cout <= 64 else "128, 2, 2")
+        return f"k_conv_gather<{tile}, false, true>", flops, byts
+    if name == "snn_conv3x3_halo_spikes":   # halo-resident forward over spikes formed from saved potentials (two products)
+        n, h, w, cin, cout = a[6], a[7], a[8], a[9], a[10]
+        flops = 2.0 * n * h * w * cout * 9 * cin
+        byts = 4.0 * (n * h * w * cin + n * h * w * cout) + 4.0 * cout * 9 * cin
+        return f"k_conv_halo3<{128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)}, fwd, spikes>", flops, byts
     if name == "snn_conv3x3_halo":   # halo-resident 3x3 / stride 1 (csrc/conv_halo.hip): forward (fp16 x 3) or data gradient
         n, h, w, cin, cout, prec = a[5], a[6], a[7], a[8], a[9], a[17]
         es = 2.0 if prec == PREC_BF16S else 4.0
